@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions (imported from
+/root/reference with audio/GUI modules stubbed) on synthetic frames.
+
+Run in the build container only:  python tools/make_goldens.py
+The reference never travels; only the resulting data files are committed.
+Each .npz records numpy/scipy versions -- the reference pins none, so the oracle is defined as
+"the reference's code on the numpy/scipy of this image".
+"""
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import scipy
+
+import ref_stubs
+
+ref_stubs.install()
+_scratch = tempfile.mkdtemp(prefix="refimport_")   # importing opens sonar.log in the CWD
+os.chdir(_scratch)
+sys.path.insert(0, "/root/reference")
+
+from dsp_amd import config as C          # noqa: E402
+from dsp_amd.synth import synth_frame_i16, quantise   # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class _Self:
+    temperature = 20.0
+
+
+def edge_frames(cfg, tx_mix, rng):
+    """int16 frames for the edge cases: silence, noise only, echo in the blind zone, echo in the
+    detectable half, two equal echoes, clipped input."""
+    n, m = cfg.n_rx, len(tx_mix)
+    frames, names = [], []
+
+    def put(name, x):
+        frames.append(quantise(x)); names.append(name)
+
+    put("silence", np.zeros(n))
+    put("noise_only", rng.normal(0, 0.01, n))
+    lag_blind = cfg.half - (m - 1) + cfg.min_delay // 2      # peak lands inside pos[:min_delay]
+    x = rng.normal(0, 0.003, n); x[lag_blind:lag_blind + m] += 0.3 * tx_mix[: max(0, min(m, n - lag_blind))]
+    put("echo_in_blind_zone", x)
+    lag_far = cfg.half - (m - 1) + cfg.min_delay + 700
+    x = rng.normal(0, 0.003, n); k = min(m, n - lag_far); x[lag_far:lag_far + k] += 0.3 * tx_mix[:k]
+    put("echo_far", x)
+    x = rng.normal(0, 0.003, n)
+    for lag in (lag_far - 300, lag_far + 500):
+        k = min(m, n - lag); x[lag:lag + k] += 0.25 * tx_mix[:k]
+    put("two_equal_echoes", x)
+    x = rng.normal(0, 0.4, n); k = min(m, n - lag_far); x[lag_far:lag_far + k] += 3.0 * tx_mix[:k]
+    put("clipped", x)
+    lag_end = n - m // 2                                      # echo truncated by the frame end
+    x = rng.normal(0, 0.003, n); k = n - lag_end; x[lag_end:] += 0.3 * tx_mix[:k]
+    put("echo_truncated", x)
+    return np.stack(frames), names
+
+
+def run_optimized(tag, bands, n_random=24, n_full=3):
+    """airSonar_optimized.py on both band sets: per-stage arrays for a few frames, scalars for all."""
+    import importlib
+    import airSonar_optimized as ref
+    # the module-level cfg is frozen; rebuild it with the wanted bands
+    ref.cfg = ref.Config(BANDS=tuple(bands))
+    cfg = C.optimized_config(bands)
+    assert not ref.GPU_AVAILABLE
+    tx_pcm, chirps = ref.generate_chirps(ref.cfg.FS, ref.cfg.CHIRP_LEN)
+    filters = ref.design_filters(ref.cfg.FS)
+    assert len(tx_pcm) == cfg.n_chirp and int(ref.cfg.FS * ref.cfg.LISTEN_LEN) == cfg.n_rx
+    tx_mix = tx_pcm.astype(np.float64) / 32768.0
+    rnd = np.stack([synth_frame_i16(i, cfg, tx_mix) for i in range(n_random)])
+    edge, edge_names = edge_frames(cfg, tx_mix, np.random.default_rng(99))
+    rx_i16 = np.concatenate([rnd, edge])
+    B, nb = len(rx_i16), len(bands)
+    rx = rx_i16.astype(np.float32) / 2 ** 15
+    g = dict(rx_i16=rx_i16, edge_names=np.array(edge_names), n_random=n_random,
+             tx_pcm=tx_pcm, chirps=np.stack(chirps),
+             filt_b=np.stack([f[0] for f in filters]), filt_a=np.stack([f[1] for f in filters]),
+             filt_taps=np.stack([f[2] for f in filters]),
+             numpy_version=np.__version__, scipy_version=scipy.__version__, bands=np.array(bands))
+    peak = np.full((B, nb), -1, np.int32); snr = np.zeros((B, nb)); amp = np.zeros((B, nb))
+    dist = np.zeros((B, nb)); conf = np.zeros((B, nb)); valid = np.zeros((B, nb), bool)
+    full_dist = np.zeros((B, nb)); full_conf = np.zeros((B, nb)); full_snr = np.zeros((B, nb))
+    full_valid = np.zeros((B, nb), bool)
+    fused = np.zeros(B); avgc = np.zeros(B); vany = np.zeros(B, bool); kal = np.zeros(B)
+    ffused = np.zeros(B); favgc = np.zeros(B); fvany = np.zeros(B, bool); fkal = np.zeros(B)
+    full_idx = list(range(n_full)) + list(range(n_random, B))      # frames with per-stage arrays
+    st_band = np.zeros((len(full_idx), nb, cfg.n_rx)); st_spec = np.zeros((len(full_idx), nb, cfg.n_bins))
+    st_corr = np.zeros((len(full_idx), nb, cfg.n_corr)); st_corr_after = np.zeros_like(st_corr)
+    st_env = np.zeros_like(st_corr)
+    sigq = np.zeros((B, nb)); corrq = np.zeros((B, nb))
+    kf = ref.ScalarKalman(); kf_full = ref.ScalarKalman()
+    me = _Self()
+    for i in range(B):
+        res_named, res_full = [], []
+        for j in range(nb):
+            # ---- named chain: the first_strong_peak path of _process_band_gpu (lines 633, 639, 657-667)
+            band_sig = ref.bandpass(rx[i], filters[j])
+            spec = ref.mag2db(np.fft.rfft(band_sig))
+            corr = ref.gpu_correlate(band_sig, chirps[j])
+            corr_raw = corr.copy()
+            p, s = ref.first_strong_peak(corr, ref.cfg.FS, cfg.min_delay)
+            a = float(np.max(np.abs(corr)))
+            amp[i, j] = a
+            if p is not None:
+                peak[i, j] = p; snr[i, j] = s; valid[i, j] = True
+                dist[i, j] = (p - (len(chirps[j]) - 1)) / ref.cfg.FS * ref.calculate_sound_speed(20.0) / 2
+                conf[i, j] = ref.calculate_band_confidence(s, a, j)
+                res_named.append((dist[i, j], conf[i, j], s))
+            # ---- full chain: the reference method itself
+            d, c, s2 = ref.SonarWorker._process_band_gpu(me, rx[i], chirps[j], filters[j], j)
+            if d is not None:
+                full_dist[i, j] = d; full_conf[i, j] = c; full_snr[i, j] = s2; full_valid[i, j] = True
+                res_full.append((d, c, s2))
+            _, _, sigq[i, j] = ref.gpu_envelope_detection(band_sig, method='hilbert', smooth_window=3)
+            env, _, corrq[i, j] = ref.gpu_envelope_detection(corr_raw, method='hilbert', smooth_window=5)
+            if i in full_idx:
+                k = full_idx.index(i)
+                st_band[k, j] = band_sig; st_spec[k, j] = spec; st_corr[k, j] = corr_raw
+                st_corr_after[k, j] = corr; st_env[k, j] = env
+        for results, (fa, aa, va, ka, kfi) in ((res_named, (fused, avgc, vany, kal, kf)),
+                                                (res_full, (ffused, favgc, fvany, fkal, kf_full))):
+            if results:   # airSonar_optimized.py:733-739
+                distances, confidences, snrs = zip(*results)
+                cn = ref.normalize_confidences(confidences)
+                w = cn / 100.0 + 1e-9
+                fa[i] = np.average(distances, weights=w); aa[i] = np.mean(cn); va[i] = True
+                ka[i] = kfi.update(fa[i])
+            else:
+                ka[i] = kfi.x if kfi.x is not None else 0.0
+    g.update(peak_idx=peak, snr_db=snr, amplitude=amp, distance=dist, confidence=conf, valid=valid,
+             fused_dist=fused, avg_conf=avgc, valid_any=vany, kalman=kal,
+             full_distance=full_dist, full_confidence=full_conf, full_snr=full_snr, full_valid=full_valid,
+             full_fused_dist=ffused, full_avg_conf=favgc, full_valid_any=fvany, full_kalman=fkal,
+             signal_quality=sigq, corr_quality=corrq,
+             stage_frames=np.array(full_idx), stage_band_sig=st_band, stage_spec_db=st_spec.astype(np.float32),
+             stage_corr=st_corr, stage_corr_after=st_corr_after, stage_corr_envelope=st_env.astype(np.float32))
+    path = os.path.join(GOLD, f"optimized_{tag}.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB",
+          "valid named", int(valid.sum()), "of", valid.size, "full", int(full_valid.sum()))
+
+
+def run_original(n_random=6):
+    """airSonar.py (config 4): IIR 8 / FIR 101, N = 8820, M = 4410, MAD first-crossing detector."""
+    import airSonar as ref
+    cfg = C.original_config()
+    tx_pcm, chirps = ref.generate_chirps()
+    filters = ref.design_filters()
+    assert len(tx_pcm) == cfg.n_chirp and int(ref.FS * ref.LISTEN_LEN) == cfg.n_rx
+    tx_mix = tx_pcm.astype(np.float64) / 32768.0
+    rx_i16 = np.stack([synth_frame_i16(i, cfg, tx_mix) for i in range(n_random)]
+                      + [quantise(np.zeros(cfg.n_rx))])
+    rx = rx_i16.astype(np.float32) / 2 ** 15
+    B, nb = len(rx), len(filters)
+    peak = np.full((B, nb), -1, np.int32); dist = np.zeros((B, nb)); valid = np.zeros((B, nb), bool)
+    fused = np.zeros(B); vany = np.zeros(B, bool); kal = np.zeros(B)
+    band0 = np.zeros((nb, cfg.n_rx)); corr0 = np.zeros((nb, cfg.n_corr))
+    kf = ref.ScalarKalman(); me = _Self()
+    for i in range(B):
+        ds = []
+        for j in range(nb):
+            y = ref.bandpass(rx[i], filters[j])
+            corr = ref.correlate(y, chirps[j], 'full')
+            if i == 0:
+                band0[j] = y; corr0[j] = corr
+            p = ref.first_strong_peak(corr, ref.FS)
+            d = ref.SonarWorker._process_band(me, rx[i], chirps[j], filters[j])
+            if p is not None:
+                peak[i, j] = p; valid[i, j] = True; dist[i, j] = d; ds.append(d)
+            else:
+                assert d is None
+        if ds:
+            fused[i] = float(np.mean(ds)); vany[i] = True; kal[i] = kf.update(fused[i])
+        else:
+            kal[i] = kf.x if kf.x is not None else 0.0
+    path = os.path.join(GOLD, "original.npz")
+    np.savez_compressed(path, rx_i16=rx_i16, tx_pcm=tx_pcm, chirps=np.stack(chirps),
+                        filt_b=np.stack([f[0] for f in filters]), filt_a=np.stack([f[1] for f in filters]),
+                        filt_taps=np.stack([f[2] for f in filters]),
+                        peak_idx=peak, distance=dist, valid=valid, fused_dist=fused, valid_any=vany, kalman=kal,
+                        stage_band_sig0=band0, stage_corr0=corr0,
+                        numpy_version=np.__version__, scipy_version=scipy.__version__)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "valid", int(valid.sum()), "of", valid.size)
+
+
+def run_realtime(n_streams=4, n_steps=6):
+    """realtime_sonar.py (config 5): S streams x T frames, its detector / confidence / fusion / Kalman."""
+    import realtime_sonar as ref
+    cfg = C.realtime_config()
+    tx_pcm, chirps = ref.generate_chirps()
+    filters = ref.design_filters()
+    assert len(tx_pcm) == cfg.n_chirp and int(ref.cfg.FS * ref.cfg.LISTEN_LEN) == cfg.n_rx
+    tx_mix = tx_pcm.astype(np.float64) / 32768.0
+    B = n_streams * n_steps
+    rx_i16 = np.stack([synth_frame_i16(i, cfg, tx_mix) for i in range(B)])
+    rx = rx_i16.astype(np.float32) / 2 ** 15
+    nb = len(filters)
+    peak = np.full((B, nb), -1, np.int32); snr = np.zeros((B, nb)); dist = np.zeros((B, nb))
+    conf = np.zeros((B, nb)); valid = np.zeros((B, nb), bool); amp = np.zeros((B, nb))
+    fused = np.zeros(B); avgc = np.zeros(B); vany = np.zeros(B, bool); kal = np.zeros(B)
+    kfs = [ref.ScalarKalman() for _ in range(n_streams)]
+    me = _Self()
+    for i in range(B):            # time-major: stream = i % S
+        res = []
+        for j in range(nb):
+            y = ref.gpu_bandpass(rx[i], filters[j])
+            corr = ref.gpu_correlate(y, chirps[j])
+            p, s = ref.first_strong_peak(corr, ref.cfg.FS)
+            amp[i, j] = np.max(np.abs(corr))
+            d, c, s2 = ref.SonarWorker._process_band(me, rx[i], chirps[j], filters[j], j)
+            if p is not None:
+                peak[i, j] = p; snr[i, j] = s; valid[i, j] = True; dist[i, j] = d; conf[i, j] = c
+                res.append((d, c, s2))
+            else:
+                assert d is None
+        kf = kfs[i % n_streams]
+        if res:
+            distances, confs, snrs = zip(*res)
+            nc = ref.normalize_confidences(confs)
+            w = nc / 100.0
+            fused[i] = np.average(distances, weights=w); avgc[i] = np.mean(nc); vany[i] = True
+            kal[i] = kf.update(fused[i])
+        else:
+            kal[i] = kf.x if kf.x is not None else 0.0
+    path = os.path.join(GOLD, "realtime.npz")
+    np.savez_compressed(path, rx_i16=rx_i16, n_streams=n_streams, tx_pcm=tx_pcm, chirps=np.stack(chirps),
+                        filt_b=np.stack([f[0] for f in filters]), filt_a=np.stack([f[1] for f in filters]),
+                        filt_taps=np.stack([f[2] for f in filters]),
+                        peak_idx=peak, snr_db=snr, amplitude=amp, distance=dist, confidence=conf, valid=valid,
+                        fused_dist=fused, avg_conf=avgc, valid_any=vany, kalman=kal,
+                        numpy_version=np.__version__, scipy_version=scipy.__version__)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "valid", int(valid.sum()), "of", valid.size)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    run_optimized("default", C.BANDS_DEFAULT)
+    run_optimized("distinct", C.BANDS_DISTINCT)
+    run_original()
+    run_realtime()
