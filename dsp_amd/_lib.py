@@ -1,0 +1,78 @@
+"""ctypes binding of libechohip.so (the C ABI declared in include/echo_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libechohip.so")
+MAX_BANDS = 3
+
+EXPORTS = [
+    "echo_create", "echo_destroy", "echo_reserve", "echo_strerror", "echo_version",
+    "echo_fir_bank", "echo_bandpass_bank", "echo_spectrum", "echo_mag2db", "echo_correlate",
+    "echo_first_strong_peak", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
+    "echo_chain", "echo_set_profiling", "echo_last_kernel_ms",
+]
+
+
+class EchoError(RuntimeError):
+    pass
+
+
+class EchoConfigC(C.Structure):
+    _fields_ = [
+        ("fs", C.c_int32), ("n_rx", C.c_int32), ("n_chirp", C.c_int32), ("n_bands", C.c_int32),
+        ("iir_ncoef", C.c_int32), ("n_taps", C.c_int32), ("min_delay", C.c_int32), ("noise_n", C.c_int32),
+        ("detector", C.c_int32), ("confidence", C.c_int32), ("fusion", C.c_int32), ("range_offset", C.c_int32),
+        ("snr_gate_db", C.c_double), ("sound_speed", C.c_double), ("kalman_q", C.c_double), ("kalman_r", C.c_double),
+        ("freq_weights", C.c_double * MAX_BANDS),
+        ("b", C.c_void_p), ("a", C.c_void_p), ("zi", C.c_void_p), ("taps", C.c_void_p), ("chirps", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libechohip.so once; raises EchoError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EchoError(f"{LIB_PATH} not found: build it with `make -C dsp_amd/csrc` "
+                        "(or python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(LIB_PATH)
+    P, I = C.c_void_p, C.c_int
+    lib.echo_create.argtypes = [C.POINTER(EchoConfigC), C.POINTER(P)]
+    lib.echo_destroy.argtypes = [P]; lib.echo_destroy.restype = None
+    lib.echo_reserve.argtypes = [P, I]
+    lib.echo_strerror.argtypes = [I]; lib.echo_strerror.restype = C.c_char_p
+    lib.echo_version.argtypes = []; lib.echo_version.restype = C.c_char_p
+    lib.echo_fir_bank.argtypes = [P, P, P, I, P]
+    lib.echo_bandpass_bank.argtypes = [P, P, P, I, P]
+    lib.echo_spectrum.argtypes = [P, P, P, I, I, P]
+    lib.echo_mag2db.argtypes = [P, P, C.c_size_t, P]
+    lib.echo_correlate.argtypes = [P, P, P, I, P]
+    lib.echo_first_strong_peak.argtypes = [P, P, P, P, P, I, P]
+    lib.echo_argmax.argtypes = [P, P, I, I, P]
+    lib.echo_confidence_fuse.argtypes = [P, P, P, P, P, I, P]
+    lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.echo_set_profiling.argtypes = [P, I]
+    lib.echo_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:
+            pass
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().echo_strerror(rc).decode()
+        raise EchoError(f"{what} failed: {msg} ({rc})")

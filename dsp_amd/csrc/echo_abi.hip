@@ -1,0 +1,338 @@
+// extern "C" entry points of libechohip.so (declared in include/echo_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/echo_hip.h"
+#include "echo_internal.h"
+#include "tables.h"
+
+using namespace echo;
+
+struct EchoHandle {
+    EchoConfig cfg;
+    int device = 0;
+    bool bodd0 = false;
+    BandParams base;                       // sizes, layout and device table pointers
+    // device constant tables
+    double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
+    float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_unpack = nullptr;
+    // grow-only scratch, sized for cap_frames frames
+    int cap_frames = 0;
+    double* d_fwd = nullptr;               // IIR forward-pass output
+    double* d_y = nullptr;                 // IIR result
+    BandRes* d_res = nullptr;
+    double* d_fused = nullptr;
+    uint8_t* d_vany = nullptr;
+    int max_chunk = 16384;                 // frames per internal pass of echo_chain
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms[3] = {0, 0, 0};
+    int prof_launches = 0;
+};
+
+namespace {
+
+template <class T> int dev_upload(T** dst, const T* src, size_t n) {
+    if (hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T)) != hipSuccess) return ECHO_ERR_NOMEM;
+    if (hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return ECHO_ERR_HIP;
+    return ECHO_OK;
+}
+
+void free_scratch(EchoHandle* h) {
+    hipFree(h->d_fwd); hipFree(h->d_y); hipFree(h->d_res); hipFree(h->d_fused); hipFree(h->d_vany);
+    h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
+    h->cap_frames = 0;
+}
+
+int ensure_scratch(EchoHandle* h, int frames) {
+    if (frames <= h->cap_frames) return ECHO_OK;
+    free_scratch(h);
+    const EchoConfig& c = h->cfg;
+    const int P = 3 * c.iir_ncoef;
+    const size_t ntiles = (size_t)(frames + 63) / 64;
+    const size_t fwd_n = (size_t)c.n_bands * ntiles * (size_t)(c.n_rx + 2 * P) * 64;
+    const size_t y_n = (size_t)frames * c.n_bands * c.n_rx;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_fwd), fwd_n * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_y), y_n * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_vany), (size_t)frames) != hipSuccess) {
+        free_scratch(h);
+        return ECHO_ERR_NOMEM;
+    }
+    h->cap_frames = frames;
+    return ECHO_OK;
+}
+
+IirParams iir_params(EchoHandle* h, const float* rx, double* y, int B) {
+    IirParams p;
+    p.rx = rx; p.y = y; p.fwd = h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
+    p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands; p.ntiles = (B + 63) / 64;
+    return p;
+}
+
+FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, double* fused, uint8_t* vany, int B) {
+    FuseParams p;
+    p.res = res; p.out = out; p.fused = fused; p.valid_any = vany;
+    p.B = B; p.nb = h->cfg.n_bands; p.fs = h->cfg.fs; p.range_offset = h->cfg.range_offset;
+    p.confidence = h->cfg.confidence; p.fusion = h->cfg.fusion; p.sound_speed = h->cfg.sound_speed;
+    for (int j = 0; j < 3; ++j) p.fw[j] = h->cfg.freq_weights[j];
+    return p;
+}
+
+bool detector_supported(int d) { return d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW; }
+
+}  // namespace
+
+extern "C" {
+
+const char* echo_version(void) { return "echohip 0.1 gfx950"; }
+
+const char* echo_strerror(int code) {
+    switch (code) {
+        case ECHO_OK: return "ok";
+        case ECHO_ERR_INVALID: return "invalid argument";
+        case ECHO_ERR_UNSUPPORTED: return "configuration not supported by this build's kernels";
+        case ECHO_ERR_NOMEM: return "device allocation failed";
+        case ECHO_ERR_HIP: return "HIP runtime call or kernel launch failed";
+        case ECHO_ERR_NODEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+int echo_create(const EchoConfig* cfg, EchoHandle** out) {
+    if (!cfg || !out) return ECHO_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_bands < 1 || cfg->n_bands > ECHO_MAX_BANDS || !cfg->b || !cfg->a || !cfg->zi || !cfg->taps ||
+        !cfg->chirps || cfg->n_rx < 64 || cfg->n_chirp < 1 || cfg->n_taps < 1 || cfg->fs <= 0)
+        return ECHO_ERR_INVALID;
+    if (cfg->iir_ncoef != 13 && cfg->iir_ncoef != 17) return ECHO_ERR_UNSUPPORTED;
+    if (3 * cfg->iir_ncoef + 1 > 64 || 3 * cfg->iir_ncoef >= cfg->n_rx) return ECHO_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ECHO_ERR_NODEVICE;
+    EchoHandle* h = new (std::nothrow) EchoHandle();
+    if (!h) return ECHO_ERR_NOMEM;
+    h->cfg = *cfg;
+    hipGetDevice(&h->device);
+    std::memset(&h->base, 0, sizeof(h->base));
+    if (!plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay, cfg->noise_n,
+                   cfg->detector, cfg->snr_gate_db)) {
+        delete h;
+        return ECHO_ERR_UNSUPPORTED;
+    }
+    const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
+    h->bodd0 = true;
+    for (int j = 0; j < nb; ++j)
+        for (int k = 1; k < nc; k += 2)
+            if (cfg->b[j * nc + k] != 0.0) h->bodd0 = false;
+    for (int j = 0; j < nb; ++j)
+        if (cfg->a[j * nc] != 1.0) { delete h; return ECHO_ERR_INVALID; }   // tables must be a0-normalised
+    HostTables t;
+    build_tables(t, h->base, cfg->taps, cfg->chirps);
+    int rc = ECHO_OK;
+    auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
+    up(dev_upload(&h->d_b, cfg->b, (size_t)nb * nc));
+    up(dev_upload(&h->d_a, cfg->a, (size_t)nb * nc));
+    up(dev_upload(&h->d_zi, cfg->zi, (size_t)nb * (nc - 1)));
+    up(dev_upload(&h->d_taps_rev, t.taps_rev.data(), t.taps_rev.size()));
+    up(dev_upload(&h->d_chirp, t.chirp.data(), t.chirp.size()));
+    up(dev_upload(&h->d_bw, t.bw.data(), t.bw.size()));
+    up(dev_upload(&h->d_bhat, t.bhat.data(), t.bhat.size()));
+    up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
+    up(dev_upload(&h->d_unpack, t.unpack.data(), t.unpack.size()));
+    if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes);
+    if (rc != ECHO_OK) { echo_destroy(h); return rc; }
+    h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
+    h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.unpack = h->d_unpack;
+    // the cfg table pointers are host pointers owned by the caller; do not keep them
+    h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
+    *out = h;
+    return ECHO_OK;
+}
+
+void echo_destroy(EchoHandle* h) {
+    if (!h) return;
+    free_scratch(h);
+    hipFree(h->d_b); hipFree(h->d_a); hipFree(h->d_zi); hipFree(h->d_taps_rev); hipFree(h->d_chirp);
+    hipFree(h->d_bw); hipFree(h->d_bhat); hipFree(h->d_tw); hipFree(h->d_unpack);
+    for (auto& e : h->ev) if (e) hipEventDestroy(e);
+    delete h;
+}
+
+int echo_reserve(EchoHandle* h, int max_frames) {
+    if (!h || max_frames < 1) return ECHO_ERR_INVALID;
+    return ensure_scratch(h, std::min(max_frames, h->max_chunk));
+}
+
+int echo_set_profiling(EchoHandle* h, int enable) {
+    if (!h) return ECHO_ERR_INVALID;
+    h->prof = enable != 0;
+    if (h->prof)
+        for (auto& e : h->ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
+    return ECHO_OK;
+}
+
+int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms) {
+    if (!h || !h->prof || !h->ev[3]) return ECHO_ERR_INVALID;
+    if (hipEventSynchronize(h->ev[3]) != hipSuccess) return ECHO_ERR_HIP;
+    float a = 0, b = 0, c = 0;
+    if (hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess ||
+        hipEventElapsedTime(&b, h->ev[1], h->ev[2]) != hipSuccess ||
+        hipEventElapsedTime(&c, h->ev[2], h->ev[3]) != hipSuccess) return ECHO_ERR_HIP;
+    if (iir_ms) *iir_ms = a;
+    if (band_ms) *band_ms = b;
+    if (fuse_ms) *fuse_ms = c;
+    return ECHO_OK;
+}
+
+int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream) {
+    if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
+    BandParams p = h->base;
+    p.mode = MODE_RX_FIR; p.do_corr = 0; p.do_spec = 0; p.rx_in = rx; p.band_out = out;
+    return launch_band(p, B, static_cast<hipStream_t>(stream));
+}
+
+int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, void* stream) {
+    if (!h || !rx || !band_sig || B < 0) return ECHO_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+        const int n = std::min(h->max_chunk, B - f0);
+        int rc = ensure_scratch(h, n);
+        if (rc) return rc;
+        const size_t o = (size_t)f0 * h->cfg.n_bands * h->cfg.n_rx;
+        rc = launch_iir(iir_params(h, rx + (size_t)f0 * h->cfg.n_rx, h->d_y, n), h->cfg.iir_ncoef, h->bodd0, s);
+        if (rc) return rc;
+        BandParams p = h->base;
+        p.mode = MODE_Y_FIR; p.do_corr = 0; p.do_spec = 0; p.d_in = h->d_y; p.band_out = band_sig + o;
+        rc = launch_band(p, n, s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
+int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
+    if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
+    BandParams p = h->base;
+    p.mode = MODE_BAND; p.do_corr = 0; p.do_spec = 1; p.spec_db = db ? 1 : 0; p.d_in = band_sig; p.spec_out = spec;
+    return launch_band(p, B, static_cast<hipStream_t>(stream));
+}
+
+int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
+    if ((!x || !out) && n) return ECHO_ERR_INVALID;
+    return launch_mag2db(x, out, n, static_cast<hipStream_t>(stream));
+}
+
+int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream) {
+    if (!h || !band_sig || !corr || B < 0) return ECHO_ERR_INVALID;
+    BandParams p = h->base;
+    p.mode = MODE_BAND; p.do_corr = 1; p.do_spec = 0; p.d_in = band_sig; p.corr_io = corr; p.res_out = nullptr;
+    return launch_band(p, B, static_cast<hipStream_t>(stream));
+}
+
+int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db, double* amplitude,
+                           int B, void* stream) {
+    if (!h || !corr || !peak_idx || !snr_db || B < 0) return ECHO_ERR_INVALID;
+    if (!detector_supported(h->cfg.detector)) return ECHO_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = h->cfg.n_bands;
+    for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+        const int n = std::min(h->max_chunk, B - f0);
+        int rc = ensure_scratch(h, n);
+        if (rc) return rc;
+        BandParams p = h->base;
+        p.mode = MODE_CORR; p.do_corr = 1; p.do_spec = 0; p.write_corr_mutated = 1;
+        p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->d_res;
+        rc = launch_band(p, n, s);
+        if (rc) return rc;
+        rc = launch_unpack_res(h->d_res, peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb,
+                               amplitude ? amplitude + (size_t)f0 * nb : nullptr, n * nb, s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
+int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream) {
+    if (!x || !out || rows < 0 || n < 1) return ECHO_ERR_INVALID;
+    return launch_argmax(x, out, rows, n, static_cast<hipStream_t>(stream));
+}
+
+int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* snr_db, const double* amplitude,
+                         EchoResult* out, int B, void* stream) {
+    if (!h || !peak_idx || !snr_db || !amplitude || !out || B < 0) return ECHO_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = h->cfg.n_bands;
+    for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+        const int n = std::min(h->max_chunk, B - f0);
+        int rc = ensure_scratch(h, n);
+        if (rc) return rc;
+        rc = launch_pack_res(peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb, amplitude + (size_t)f0 * nb,
+                             h->d_res, n * nb, s);
+        if (rc) return rc;
+        rc = launch_fuse(fuse_params(h, h->d_res, out + f0, nullptr, nullptr, n), s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
+int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid,
+                       double* out, int S, int T, void* stream) {
+    if (!h || !x || !p || !init || !z || !valid || S < 0 || T < 0) return ECHO_ERR_INVALID;
+    KalmanParams k;
+    k.x = x; k.p = p; k.init = init; k.z = z; k.valid = valid; k.out = out; k.rec = nullptr;
+    k.S = S; k.T = T; k.q = h->cfg.kalman_q; k.r = h->cfg.kalman_r;
+    return launch_kalman(k, static_cast<hipStream_t>(stream));
+}
+
+int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
+               uint8_t* kalman_init, int B, int n_streams, void* stream) {
+    if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
+    const bool kal = kalman_x || kalman_p || kalman_init;
+    if (kal && (!kalman_x || !kalman_p || !kalman_init || n_streams < 1 || B % n_streams != 0)) return ECHO_ERR_INVALID;
+    if (!detector_supported(h->cfg.detector)) return ECHO_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = h->cfg.n_bands, N = h->cfg.n_rx;
+    // frames are processed in passes of at most max_chunk; with a Kalman state each pass must hold whole
+    // time steps (multiples of n_streams) so the time-major order is preserved
+    int chunk = h->max_chunk;
+    if (kal) {
+        if (n_streams > chunk) chunk = n_streams;          // one time step per pass at least
+        else chunk = (chunk / n_streams) * n_streams;
+    }
+    for (int f0 = 0; f0 < B; f0 += chunk) {
+        const int n = std::min(chunk, B - f0);
+        int rc = ensure_scratch(h, n);
+        if (rc) return rc;
+        const bool prof = h->prof && f0 == 0;
+        if (prof) hipEventRecord(h->ev[0], s);
+        rc = launch_iir(iir_params(h, rx + (size_t)f0 * N, h->d_y, n), h->cfg.iir_ncoef, h->bodd0, s);
+        if (rc) return rc;
+        if (prof) hipEventRecord(h->ev[1], s);
+        BandParams p = h->base;
+        p.mode = MODE_Y_FIR; p.do_corr = 1; p.do_spec = spec_db ? 1 : 0; p.spec_db = 1;
+        p.d_in = h->d_y; p.res_out = h->d_res;
+        p.spec_out = spec_db ? spec_db + (size_t)f0 * nb * p.nbins : nullptr;
+        rc = launch_band(p, n, s);
+        if (rc) return rc;
+        if (prof) hipEventRecord(h->ev[2], s);
+        rc = launch_fuse(fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n), s);
+        if (rc) return rc;
+        if (kal) {
+            KalmanParams k;
+            k.x = kalman_x; k.p = kalman_p; k.init = kalman_init; k.z = h->d_fused; k.valid = h->d_vany;
+            k.out = nullptr; k.rec = out + f0; k.S = n_streams; k.T = n / n_streams;
+            k.q = h->cfg.kalman_q; k.r = h->cfg.kalman_r;
+            rc = launch_kalman(k, s);
+            if (rc) return rc;
+        }
+        if (prof) hipEventRecord(h->ev[3], s);
+    }
+    return ECHO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// Internal declarations shared by the translation units of libechohip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "band_phases.h"
+
+namespace echo {
+
+struct IirParams {
+    const float* rx;      // [B][N]
+    double* y;            // [B][nb][N]   zero-phase IIR output
+    double* fwd;          // [nb][ntiles][N+2P][64] forward-pass scratch
+    const double* b;      // [nb][NC]
+    const double* a;      // [nb][NC]
+    const double* zi;     // [nb][NC-1]
+    int B, N, P, nb, ntiles;
+};
+
+struct FuseParams {
+    const BandRes* res;   // [B][nb]
+    void* out;            // EchoResult[B]
+    double* fused;        // [B] (may be null)
+    uint8_t* valid_any;   // [B] (may be null)
+    int B, nb, fs, range_offset, confidence, fusion;
+    double sound_speed;
+    double fw[3];
+};
+
+struct KalmanParams {
+    double* x; double* p; uint8_t* init;      // [S]
+    const double* z; const uint8_t* valid;    // [T][S]
+    double* out;                              // [T][S] (may be null)
+    void* rec;                                // EchoResult[T*S] (may be null): .kalman is filled
+    int S, T;
+    double q, r;
+};
+
+int launch_iir(const IirParams& p, int ncoef, bool bodd0, hipStream_t s);
+int launch_band(const BandParams& p, int B, hipStream_t s);
+int band_kernel_prepare(int smem_bytes);
+int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, BandRes* res, int n, hipStream_t s);
+int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s);
+int launch_fuse(const FuseParams& p, hipStream_t s);
+int launch_kalman(const KalmanParams& p, hipStream_t s);
+int launch_argmax(const double* x, int32_t* out, int rows, int n, hipStream_t s);
+int launch_mag2db(const float* x, float* out, size_t n, hipStream_t s);
+
+}  // namespace echo

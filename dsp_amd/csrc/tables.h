@@ -1,0 +1,122 @@
+// Host-side construction of the constant tables and the LDS layout of the band kernel.
+// Plain C++ (no HIP): shared by the library's echo_create and by the host emulation used in unit tests.
+#pragma once
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+#include "band_phases.h"
+
+namespace echo {
+
+struct HostTables {
+    std::vector<double> taps_rev;   // [nb][kgroups*kR]
+    std::vector<double> chirp;      // [nb][mgroups*kR]
+    std::vector<float2> bw, bhat, tw, unpack;
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int align_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// In-place iterative radix-2 FFT, double precision, forward sign.
+inline void fft_pow2(std::vector<std::complex<double>>& a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    const double pi = 3.14159265358979323846;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double ang = -2.0 * pi * (double)k / (double)len;
+                const std::complex<double> w(std::cos(ang), std::sin(ang));
+                const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v; a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+// Frequency index held at LDS position p after the forward passes (radices 8,8,8,4,4; sub-sizes 1024,128,16,4,1).
+inline int pass_order_freq(int p) {
+    const int m1 = p / 1024, m2 = (p / 128) % 8, m3 = (p / 16) % 8, m4 = (p / 4) % 4, m5 = p % 4;
+    return m1 + 8 * m2 + 64 * m3 + 512 * m4 + 2048 * m5;
+}
+
+inline float2 mk(double re, double im) { float2 r; r.x = (float)re; r.y = (float)im; return r; }
+
+// Fills the size/layout fields of BandParams that depend only on the configuration.  Returns false when the
+// configuration does not fit the kernel (frame too long for one workgroup or for the Bluestein length).
+inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay, int noise_n, int detector,
+                      double snr_gate) {
+    p.N = N; p.M = M; p.L = N + M - 1; p.half = p.L / 2; p.nb = nb; p.K = K;
+    p.min_delay = min_delay; p.detector = detector; p.snr_gate = snr_gate;
+    const int npos = p.L - p.half;
+    int nn = noise_n;
+    if (detector == 0 && min_delay + nn > npos) nn = npos > min_delay ? npos - min_delay : 0;  // numpy slice truncation
+    if (detector == 2 && nn > npos) nn = npos;
+    p.noise_n = nn;
+    p.n2 = N / 2; p.nbins = N / 2 + 1;
+    p.kgroups = ceil_div(K, kR); p.mgroups = ceil_div(M, kR);
+    if (N % 2 != 0 || N < 4 || M < 1 || K < 1) return false;
+    if (N > kNT * kR || p.L > kNT * kR) return false;
+    if (2 * p.n2 - 1 > kFftM) return false;
+    p.sig_len = align_up((ceil_div(p.L, kR) + p.mgroups + 1) * kR, 2);
+    p.ypad = K - 1 - (K - 1) / 2;
+    p.ybuf_len = align_up((ceil_div(N, kR) + p.kgroups + 1) * kR, 2);
+    int off = 0;
+    p.off_sig = off; off += align_up(p.sig_len * 8, 16);
+    p.off_u = off;
+    int u = p.ybuf_len * 8;
+    if (u < kFftM * 8) u = kFftM * 8;
+    if (u < kNT * 28) u = kNT * 28;
+    off += align_up(u, 16);
+    p.off_nw = off; off += align_up((nn > 0 ? nn : 1) * 8, 16);
+    p.off_misc = off; off += align_up((int)sizeof(Misc), 16);
+    p.smem_bytes = off;
+    return off <= 160 * 1024;
+}
+
+inline void build_tables(HostTables& t, const BandParams& p, const double* taps, const double* chirps) {
+    const double pi = 3.14159265358979323846;
+    const int nb = p.nb, K = p.K, M = p.M, n2 = p.n2, N = p.N;
+    t.taps_rev.assign((size_t)nb * p.kgroups * kR, 0.0);
+    t.chirp.assign((size_t)nb * p.mgroups * kR, 0.0);
+    for (int b = 0; b < nb; ++b) {
+        for (int j = 0; j < K; ++j) t.taps_rev[(size_t)b * p.kgroups * kR + j] = taps[(size_t)b * K + (K - 1 - j)];
+        for (int j = 0; j < M; ++j) t.chirp[(size_t)b * p.mgroups * kR + j] = chirps[(size_t)b * M + j];
+    }
+    // Bluestein chirp w[n] = exp(-i*pi*n^2/n2); n^2 reduced mod 2*n2 in integers so the phase stays exact
+    std::vector<std::complex<double>> w(n2);
+    t.bw.resize(n2);
+    for (int n = 0; n < n2; ++n) {
+        const long long r = ((long long)n * n) % (2LL * n2);
+        const double ang = -pi * (double)r / (double)n2;
+        w[n] = std::complex<double>(std::cos(ang), std::sin(ang));
+        t.bw[n] = mk(w[n].real(), w[n].imag());
+    }
+    std::vector<std::complex<double>> bc(kFftM, std::complex<double>(0, 0));
+    bc[0] = std::conj(w[0]);
+    for (int n = 1; n < n2; ++n) { bc[n] = std::conj(w[n]); bc[kFftM - n] = std::conj(w[n]); }
+    fft_pow2(bc);
+    t.bhat.resize(kFftM);
+    for (int pos = 0; pos < kFftM; ++pos) {
+        const std::complex<double> v = bc[pass_order_freq(pos)] / (double)kFftM;
+        t.bhat[pos] = mk(v.real(), v.imag());
+    }
+    t.tw.resize(kFftM);
+    for (int k = 0; k < kFftM; ++k) {
+        const double ang = -2.0 * pi * (double)k / (double)kFftM;
+        t.tw[k] = mk(std::cos(ang), std::sin(ang));
+    }
+    t.unpack.resize(n2 + 1);
+    for (int k = 0; k <= n2; ++k) {
+        const double ang = -2.0 * pi * (double)k / (double)N;
+        t.unpack[k] = mk(std::cos(ang), std::sin(ang));
+    }
+}
+
+}  // namespace echo

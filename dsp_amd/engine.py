@@ -1,0 +1,208 @@
+"""Batched echo-ranging engine: the host-side mirror of the reference's DSP function surface.
+
+One ``EchoEngine`` owns one library handle on one GPU.  Its methods carry the reference's function names
+with a leading batch dimension and take/return torch tensors resident in HBM (torch is used only for
+device memory and streams).  The module-level functions at the bottom are the drop-in spellings
+(``bandpass``, ``gpu_correlate``, ``first_strong_peak`` ...) that also accept host NumPy arrays the way
+the reference's CuPy wrappers do (upload, compute, download) -- airSonar_optimized.py:185-368.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import SonarConfig, optimized_config
+from .design import SonarTables, build_tables
+
+RESULT_DTYPE = np.dtype([
+    ("dist", np.float32, (3,)), ("conf", np.float32, (3,)), ("snr_db", np.float32, (3,)),
+    ("peak_idx", np.int32, (3,)), ("fused_dist", np.float32), ("avg_conf", np.float32),
+    ("kalman", np.float32), ("valid_mask", np.uint32),
+])
+assert RESULT_DTYPE.itemsize == 64
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class EchoEngine:
+    def __init__(self, cfg: Optional[SonarConfig] = None, device: Optional[torch.device] = None):
+        self.cfg = cfg or optimized_config()
+        self.tables: SonarTables = build_tables(self.cfg)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.EchoError("no GPU visible: the echo-ranging kernels need a gfx950 device")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        c, t = self.cfg, self.tables
+        self._keep = [np.ascontiguousarray(x, dtype=np.float64) for x in (t.b, t.a, t.zi, t.taps, t.chirps)]
+        cc = _lib.EchoConfigC(
+            fs=c.FS, n_rx=c.n_rx, n_chirp=c.n_chirp, n_bands=c.n_bands, iir_ncoef=2 * c.IIR_ORDER + 1,
+            n_taps=c.FIR_TAPS, min_delay=c.min_delay, noise_n=c.noise_n, detector=c.DETECTOR,
+            confidence=c.CONFIDENCE, fusion=c.FUSION, range_offset=c.range_offset, snr_gate_db=c.SNR_GATE_DB,
+            sound_speed=c.sound_speed, kalman_q=c.KALMAN_Q, kalman_r=c.KALMAN_R)
+        for j in range(3):
+            cc.freq_weights[j] = c.FREQ_WEIGHTS[j]
+        cc.b, cc.a, cc.zi, cc.taps, cc.chirps = (x.ctypes.data for x in self._keep)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.echo_create(C.byref(cc), C.byref(h)), "echo_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.echo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+    def _empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def reserve(self, max_frames: int):
+        _lib.check(self.lib.echo_reserve(self._h, int(max_frames)), "echo_reserve")
+
+    # ------------------------------------------------------------------ stages (device tensors)
+    def fir_bank(self, rx):
+        """FIR only (the reference's CuPy gpu_bandpass, airSonar_optimized.py:305-313). [B,N] f32 -> [B,nb,N] f64."""
+        rx = self._dev(rx, torch.float32)
+        B = rx.shape[0]
+        out = self._empty((B, self.cfg.n_bands, self.cfg.n_rx), torch.float64)
+        _lib.check(self.lib.echo_fir_bank(self._h, _ptr(rx), _ptr(out), B, self._stream()), "echo_fir_bank")
+        return out
+
+    def bandpass_bank(self, rx):
+        """bandpass for every band (airSonar_optimized.py:185-197). [B,N] f32 -> [B,nb,N] f64."""
+        rx = self._dev(rx, torch.float32)
+        assert rx.dim() == 2 and rx.shape[1] == self.cfg.n_rx, "rx must be [B, n_rx]"
+        B = rx.shape[0]
+        out = self._empty((B, self.cfg.n_bands, self.cfg.n_rx), torch.float64)
+        _lib.check(self.lib.echo_bandpass_bank(self._h, _ptr(rx), _ptr(out), B, self._stream()), "echo_bandpass_bank")
+        return out
+
+    def spectrum(self, band_sig, db=True):
+        """|rfft| or its dB (airSonar_optimized.py:710, :332-343). [B,nb,N] f64 -> [B,nb,N/2+1] f32."""
+        band_sig = self._dev(band_sig, torch.float64)
+        B = band_sig.shape[0]
+        out = self._empty((B, self.cfg.n_bands, self.cfg.n_bins), torch.float32)
+        _lib.check(self.lib.echo_spectrum(self._h, _ptr(band_sig), _ptr(out), 1 if db else 0, B, self._stream()),
+                   "echo_spectrum")
+        return out
+
+    def mag2db(self, x):
+        x = self._dev(x, torch.float32)
+        out = torch.empty_like(x)
+        _lib.check(self.lib.echo_mag2db(_ptr(x), _ptr(out), x.numel(), self._stream()), "echo_mag2db")
+        return out
+
+    def correlate(self, band_sig):
+        """gpu_correlate against each band's chirp (airSonar_optimized.py:290-303). -> [B,nb,L] f64."""
+        band_sig = self._dev(band_sig, torch.float64)
+        B = band_sig.shape[0]
+        out = self._empty((B, self.cfg.n_bands, self.cfg.n_corr), torch.float64)
+        _lib.check(self.lib.echo_correlate(self._h, _ptr(band_sig), _ptr(out), B, self._stream()), "echo_correlate")
+        return out
+
+    def first_strong_peak(self, corr):
+        """first_strong_peak on [B,nb,L] f64 (mutated in place). -> (peak_idx i32 [B,nb], snr_db f64, amplitude f64)."""
+        assert isinstance(corr, torch.Tensor) and corr.dtype == torch.float64 and corr.is_contiguous()
+        B = corr.shape[0]
+        nb = self.cfg.n_bands
+        peak = self._empty((B, nb), torch.int32)
+        snr = self._empty((B, nb), torch.float64)
+        amp = self._empty((B, nb), torch.float64)
+        _lib.check(self.lib.echo_first_strong_peak(self._h, _ptr(corr), _ptr(peak), _ptr(snr), _ptr(amp), B,
+                                                   self._stream()), "echo_first_strong_peak")
+        return peak, snr, amp
+
+    def argmax(self, x):
+        x = self._dev(x, torch.float64)
+        rows = int(np.prod(x.shape[:-1])) if x.dim() > 1 else 1
+        out = self._empty(x.shape[:-1] if x.dim() > 1 else (1,), torch.int32)
+        _lib.check(self.lib.echo_argmax(_ptr(x), _ptr(out), rows, x.shape[-1], self._stream()), "echo_argmax")
+        return out
+
+    def confidence_fuse(self, peak_idx, snr_db, amplitude):
+        """Range conversion + band confidence + fusion. -> uint8 tensor [B,64] viewable as RESULT_DTYPE."""
+        peak_idx = self._dev(peak_idx, torch.int32); snr_db = self._dev(snr_db, torch.float64)
+        amplitude = self._dev(amplitude, torch.float64)
+        B = peak_idx.shape[0]
+        out = self._empty((B, 64), torch.uint8)
+        _lib.check(self.lib.echo_confidence_fuse(self._h, _ptr(peak_idx), _ptr(snr_db), _ptr(amplitude), _ptr(out), B,
+                                                 self._stream()), "echo_confidence_fuse")
+        return out
+
+    def chain(self, rx, n_streams: Optional[int] = None, kalman: Optional["BatchedKalman"] = None,
+              want_spectra: bool = True, out=None, spec_out=None):
+        """The fused per-frame chain. rx [B,N] f32 (time-major over n_streams streams).
+        Returns (records uint8 [B,64], spec_db f32 [B,nb,bins] or None)."""
+        rx = self._dev(rx, torch.float32)
+        assert rx.dim() == 2 and rx.shape[1] == self.cfg.n_rx, "rx must be [B, n_rx]"
+        B = rx.shape[0]
+        if out is None:
+            out = self._empty((B, 64), torch.uint8)
+        spec = None
+        if want_spectra:
+            spec = spec_out if spec_out is not None else self._empty((B, self.cfg.n_bands, self.cfg.n_bins), torch.float32)
+        S = n_streams if n_streams is not None else (kalman.S if kalman is not None else max(B, 1))
+        kx = kp = ki = None
+        if kalman is not None:
+            assert kalman.S == S
+            kx, kp, ki = kalman.x, kalman.p, kalman.init
+        _lib.check(self.lib.echo_chain(self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(kx), _ptr(kp), _ptr(ki),
+                                       B, S, self._stream()), "echo_chain")
+        return out, spec
+
+    def set_profiling(self, on: bool):
+        _lib.check(self.lib.echo_set_profiling(self._h, 1 if on else 0), "echo_set_profiling")
+
+    def last_kernel_ms(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _lib.check(self.lib.echo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)), "echo_last_kernel_ms")
+        return {"iir": a.value, "band": b.value, "fuse": c.value}
+
+
+def records_to_numpy(rec: torch.Tensor) -> np.ndarray:
+    """uint8 [B,64] device tensor -> structured NumPy array of EchoResult rows."""
+    return rec.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+
+
+class BatchedKalman:
+    """ScalarKalman for S independent streams (airSonar_optimized.py:265-283); state lives in HBM."""
+
+    def __init__(self, engine: EchoEngine, n_streams: int):
+        self.engine = engine
+        self.S = int(n_streams)
+        d = engine.device
+        self.x = torch.zeros(self.S, dtype=torch.float64, device=d)
+        self.p = torch.ones(self.S, dtype=torch.float64, device=d)
+        self.init = torch.zeros(self.S, dtype=torch.uint8, device=d)
+
+    def update(self, z, valid=None):
+        """z [T,S] or [S] float64; valid same shape (uint8/bool). Returns smoothed values, same shape."""
+        e = self.engine
+        z = e._dev(z, torch.float64)
+        shape = z.shape
+        z2 = z.reshape(-1, self.S)
+        v = torch.ones_like(z2, dtype=torch.uint8) if valid is None else e._dev(valid, torch.uint8).reshape(-1, self.S)
+        out = torch.empty_like(z2)
+        _lib.check(e.lib.echo_kalman_update(e._h, _ptr(self.x), _ptr(self.p), _ptr(self.init), _ptr(z2), _ptr(v),
+                                            _ptr(out), self.S, z2.shape[0], e._stream()), "echo_kalman_update")
+        return out.reshape(shape)

@@ -1,0 +1,156 @@
+/*
+ * echo_hip.h -- C ABI of libechohip.so: batched echo-ranging on MI355X (gfx950).
+ *
+ * Every entry point replaces one function of the reference's accelerator seam (module-level
+ * `gpu_*` / `bandpass` / `first_strong_peak` ... functions that take host NumPy arrays, try CuPy and
+ * fall back to NumPy/SciPy).  Paths below are relative to the reference repository.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers owned by the caller, row-major, contiguous, batch-major:
+ *     rx[B][N], band_sig[B][nb][N], corr[B][nb][L], spec_db[B][nb][N/2+1].
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on it.
+ *   - Return value: 0 on success, negative ECHO_ERR_* otherwise; echo_strerror() names it.  Data-dependent
+ *     "no echo" is not an error: peak_idx = -1, snr_db = 0, valid = 0 (reference: `return None, 0.0`).
+ *   - A handle is immutable after echo_create except for its grow-only scratch; use one handle per
+ *     device and do not issue overlapping calls on the same handle from different streams.
+ */
+#ifndef ECHO_HIP_H
+#define ECHO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECHO_MAX_BANDS 3
+
+enum {
+    ECHO_OK = 0,
+    ECHO_ERR_INVALID = -1,      /* bad argument / size combination                        */
+    ECHO_ERR_UNSUPPORTED = -2,  /* configuration does not fit this build's kernels        */
+    ECHO_ERR_NOMEM = -3,        /* device allocation failed                               */
+    ECHO_ERR_HIP = -4,          /* a HIP runtime call or kernel launch failed             */
+    ECHO_ERR_NODEVICE = -5      /* no gfx950 device visible                               */
+};
+
+/* detector / confidence / fusion variants (the three first_strong_peak generations the reference ships) */
+enum { ECHO_DET_MEDIAN = 0,   /* airSonar_optimized.py:200-219 */
+       ECHO_DET_MAD = 1,      /* airSonar.py:104-117           */
+       ECHO_DET_MEANPOW = 2   /* realtime_sonar.py:127-142     */ };
+enum { ECHO_CONF_CLAMPED = 0, /* airSonar_optimized.py:222-243 */
+       ECHO_CONF_RAW = 1,     /* realtime_sonar.py:393         */
+       ECHO_CONF_NONE = 2 };
+enum { ECHO_FUSE_WEIGHTED_EPS = 0, /* airSonar_optimized.py:733-738 */
+       ECHO_FUSE_WEIGHTED = 1,     /* realtime_sonar.py:336-339     */
+       ECHO_FUSE_MEAN = 2 };       /* airSonar.py:203-205           */
+
+/* Host-side description of one sonar configuration; replaces the module-global `cfg` plus the
+ * results of design_filters()/generate_chirps() (airSonar_optimized.py:65-113, :157-183).
+ * Table pointers are HOST pointers, copied during echo_create. */
+typedef struct EchoConfig {
+    int32_t fs;            /* Config.FS                                                   */
+    int32_t n_rx;          /* samples per frame  N = int(FS*LISTEN_LEN)                   */
+    int32_t n_chirp;       /* chirp samples      M = int(FS*CHIRP_LEN)                    */
+    int32_t n_bands;       /* len(BANDS), 1..ECHO_MAX_BANDS                               */
+    int32_t iir_ncoef;     /* len(b) == len(a) == 2*order+1                               */
+    int32_t n_taps;        /* FIR length                                                  */
+    int32_t min_delay;     /* blind-zone samples int(FS*CHIRP_LEN*1.2)                    */
+    int32_t noise_n;       /* noise-window samples                                        */
+    int32_t detector;      /* ECHO_DET_*                                                  */
+    int32_t confidence;    /* ECHO_CONF_*                                                 */
+    int32_t fusion;        /* ECHO_FUSE_*                                                 */
+    int32_t range_offset;  /* delay = peak_idx - range_offset (M-1 in airSonar_optimized) */
+    double snr_gate_db;    /* 6.0                                                         */
+    double sound_speed;    /* calculate_sound_speed(temperature)                          */
+    double kalman_q, kalman_r;
+    double freq_weights[ECHO_MAX_BANDS];
+    const double* b;       /* [n_bands][iir_ncoef]   a0-normalised numerator              */
+    const double* a;       /* [n_bands][iir_ncoef]                                        */
+    const double* zi;      /* [n_bands][iir_ncoef-1] lfilter_zi(b, a)                     */
+    const double* taps;    /* [n_bands][n_taps]                                           */
+    const double* chirps;  /* [n_bands][n_chirp]                                          */
+} EchoConfig;
+
+/* Per-frame result record (64 bytes): what run() logs, emits and appends to the CSV
+ * (airSonar_optimized.py:733-747), one row per frame. */
+typedef struct EchoResult {
+    float   dist[ECHO_MAX_BANDS];      /* metres; 0 where the band is invalid             */
+    float   conf[ECHO_MAX_BANDS];      /* raw band confidence                             */
+    float   snr_db[ECHO_MAX_BANDS];
+    int32_t peak_idx[ECHO_MAX_BANDS];  /* index into pos = corr[half:], -1 = None         */
+    float   fused_dist;                /* confidence-weighted distance                    */
+    float   avg_conf;                  /* mean of normalised confidences                  */
+    float   kalman;                    /* Kalman-smoothed distance of the frame's stream  */
+    uint32_t valid_mask;               /* bit j: band j produced a range                  */
+} EchoResult;
+
+typedef struct EchoHandle EchoHandle;
+
+/* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
+ * (airSonar_optimized.py:598-619).  Uses the current HIP device. */
+int  echo_create(const EchoConfig* cfg, EchoHandle** out);
+void echo_destroy(EchoHandle* h);
+/* Pre-size the handle's scratch for batches of up to `max_frames` so later calls allocate nothing. */
+int  echo_reserve(EchoHandle* h, int max_frames);
+const char* echo_strerror(int code);
+/* Library/build identification: "echohip <version> gfx950". */
+const char* echo_version(void);
+
+/* gpu_bandpass, CuPy branch: FIR only, `cp.convolve(signal, taps, 'same')` (airSonar_optimized.py:305-313).
+ * rx[B][N] float32 -> out[B][nb][N] float64. */
+int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream);
+
+/* bandpass / gpu_bandpass CPU branch: filtfilt(b, a, sig) then fftconvolve(y, taps, 'same')
+ * (airSonar_optimized.py:185-197, :324-327).  rx[B][N] float32 -> band_sig[B][nb][N] float64. */
+int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, void* stream);
+
+/* mag2db(np.fft.rfft(band_sig)) (airSonar_optimized.py:710, :286-287; gpu_spectrum :332-343 with db=0).
+ * band_sig[B][nb][N] float64 -> spec[B][nb][N/2+1] float32.  db != 0: 20*log10(max(|X|,1e-12)); db == 0: |X|. */
+int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream);
+
+/* gpu_mag2db / mag2db on an arbitrary array (airSonar_optimized.py:345-357). */
+int echo_mag2db(const float* x, float* out, size_t n, void* stream);
+
+/* gpu_correlate: scipy.signal.correlate(a, b, 'full') against the band's chirp
+ * (airSonar_optimized.py:290-303).  band_sig[B][nb][N] -> corr[B][nb][N+M-1], float64. */
+int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream);
+
+/* first_strong_peak (airSonar_optimized.py:200-219; variants per cfg.detector).  Mutates corr exactly as the
+ * reference does (blind zone corr[half : half+min_delay] zeroed).  Also returns amplitude = max|corr| of the
+ * mutated array (airSonar_optimized.py:666) when `amplitude` is non-NULL. */
+int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db,
+                           double* amplitude, int B, void* stream);
+
+/* gpu_argmax (airSonar_optimized.py:359-368): first index of the maximum of each row of x[rows][n]. */
+int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream);
+
+/* calculate_band_confidence + range conversion + normalize_confidences + np.average fusion
+ * (airSonar_optimized.py:222-262, :662-667, :733-738).  Inputs [B][nb]; outputs per frame. */
+int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* snr_db, const double* amplitude,
+                         EchoResult* out, int B, void* stream);
+
+/* ScalarKalman.update for S independent streams (airSonar_optimized.py:265-283): T time steps,
+ * z[t*S + s]; streams whose valid[t*S+s] == 0 are skipped at that step (run() only updates when a band
+ * produced a range, :733).  State x/p/init live in caller-owned device arrays of length S. */
+int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid,
+                       double* out, int S, int T, void* stream);
+
+/* The fused per-frame chain of SonarWorker.run() for B = n_streams * T frames, time-major
+ * (frame i = stream i % n_streams at time i / n_streams): bandpass -> {rfft dB spectrum, correlate ->
+ * first_strong_peak -> confidence} -> fusion -> Kalman (airSonar_optimized.py:629-676, :703-747, envelope
+ * stages excluded).  spec_db may be NULL (no spectra stored); kalman_* may be NULL (record.kalman = fused). */
+int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
+               double* kalman_x, double* kalman_p, uint8_t* kalman_init,
+               int B, int n_streams, void* stream);
+
+/* Average device time in milliseconds of the kernels launched by the most recent echo_chain call on
+ * this handle when profiling is enabled with echo_set_profiling(h, 1) (HIP events on the call's stream). */
+int echo_set_profiling(EchoHandle* h, int enable);
+int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHO_HIP_H */
