@@ -28,11 +28,10 @@ struct EchoHandle {
     double* d_fused = nullptr;
     uint8_t* d_vany = nullptr;
     int max_chunk = 16384;                 // frames per internal pass of echo_chain
-    // profiling
+    // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    float ms[3] = {0, 0, 0};
-    int prof_launches = 0;
+    std::vector<hipEvent_t> ev;            // 4 events per slot
+    int prof_slots = 0, prof_used = 0;
 };
 
 namespace {
@@ -44,7 +43,8 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 }
 
 void free_scratch(EchoHandle* h) {
-    hipFree(h->d_fwd); hipFree(h->d_y); hipFree(h->d_res); hipFree(h->d_fused); hipFree(h->d_vany);
+    (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
+    (void)hipFree(h->d_vany);
     h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
     h->cap_frames = 0;
 }
@@ -118,7 +118,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     EchoHandle* h = new (std::nothrow) EchoHandle();
     if (!h) return ECHO_ERR_NOMEM;
     h->cfg = *cfg;
-    hipGetDevice(&h->device);
+    (void)hipGetDevice(&h->device);
     std::memset(&h->base, 0, sizeof(h->base));
     if (!plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay, cfg->noise_n,
                    cfg->detector, cfg->snr_gate_db)) {
@@ -158,9 +158,9 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
 void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
-    hipFree(h->d_b); hipFree(h->d_a); hipFree(h->d_zi); hipFree(h->d_taps_rev); hipFree(h->d_chirp);
-    hipFree(h->d_bw); hipFree(h->d_bhat); hipFree(h->d_tw); hipFree(h->d_unpack);
-    for (auto& e : h->ev) if (e) hipEventDestroy(e);
+    void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_unpack};
+    for (void* t : tabs) (void)hipFree(t);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -169,25 +169,35 @@ int echo_reserve(EchoHandle* h, int max_frames) {
     return ensure_scratch(h, std::min(max_frames, h->max_chunk));
 }
 
-int echo_set_profiling(EchoHandle* h, int enable) {
-    if (!h) return ECHO_ERR_INVALID;
-    h->prof = enable != 0;
-    if (h->prof)
-        for (auto& e : h->ev)
-            if (!e && hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
+int echo_set_profiling(EchoHandle* h, int slots) {
+    if (!h || slots < 0) return ECHO_ERR_INVALID;
+    h->prof = slots > 0;
+    h->prof_used = 0;
+    while ((int)h->ev.size() < 4 * slots) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
+        h->ev.push_back(e);
+    }
+    h->prof_slots = slots;
     return ECHO_OK;
 }
 
 int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms) {
-    if (!h || !h->prof || !h->ev[3]) return ECHO_ERR_INVALID;
-    if (hipEventSynchronize(h->ev[3]) != hipSuccess) return ECHO_ERR_HIP;
-    float a = 0, b = 0, c = 0;
-    if (hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess ||
-        hipEventElapsedTime(&b, h->ev[1], h->ev[2]) != hipSuccess ||
-        hipEventElapsedTime(&c, h->ev[2], h->ev[3]) != hipSuccess) return ECHO_ERR_HIP;
-    if (iir_ms) *iir_ms = a;
-    if (band_ms) *band_ms = b;
-    if (fuse_ms) *fuse_ms = c;
+    if (!h || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
+    double a = 0, b = 0, c = 0;
+    for (int k = 0; k < h->prof_used; ++k) {
+        hipEvent_t* e = &h->ev[4 * k];
+        if (hipEventSynchronize(e[3]) != hipSuccess) return ECHO_ERR_HIP;
+        float x = 0, y = 0, z = 0;
+        if (hipEventElapsedTime(&x, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&y, e[1], e[2]) != hipSuccess ||
+            hipEventElapsedTime(&z, e[2], e[3]) != hipSuccess) return ECHO_ERR_HIP;
+        a += x; b += y; c += z;
+    }
+    const double n = (double)h->prof_used;
+    if (iir_ms) *iir_ms = (float)(a / n);
+    if (band_ms) *band_ms = (float)(b / n);
+    if (fuse_ms) *fuse_ms = (float)(c / n);
+    h->prof_used = 0;
     return ECHO_OK;
 }
 
@@ -308,18 +318,19 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         const int n = std::min(chunk, B - f0);
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
-        const bool prof = h->prof && f0 == 0;
-        if (prof) hipEventRecord(h->ev[0], s);
+        const bool prof = h->prof && f0 == 0 && h->prof_used < h->prof_slots;
+        hipEvent_t* ev = prof ? &h->ev[4 * h->prof_used] : nullptr;
+        if (prof) (void)hipEventRecord(ev[0], s);
         rc = launch_iir(iir_params(h, rx + (size_t)f0 * N, h->d_y, n), h->cfg.iir_ncoef, h->bodd0, s);
         if (rc) return rc;
-        if (prof) hipEventRecord(h->ev[1], s);
+        if (prof) (void)hipEventRecord(ev[1], s);
         BandParams p = h->base;
         p.mode = MODE_Y_FIR; p.do_corr = 1; p.do_spec = spec_db ? 1 : 0; p.spec_db = 1;
         p.d_in = h->d_y; p.res_out = h->d_res;
         p.spec_out = spec_db ? spec_db + (size_t)f0 * nb * p.nbins : nullptr;
         rc = launch_band(p, n, s);
         if (rc) return rc;
-        if (prof) hipEventRecord(h->ev[2], s);
+        if (prof) (void)hipEventRecord(ev[2], s);
         rc = launch_fuse(fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n), s);
         if (rc) return rc;
         if (kal) {
@@ -330,7 +341,7 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
             rc = launch_kalman(k, s);
             if (rc) return rc;
         }
-        if (prof) hipEventRecord(h->ev[3], s);
+        if (prof) { (void)hipEventRecord(ev[3], s); ++h->prof_used; }
     }
     return ECHO_OK;
 }

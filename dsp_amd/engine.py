@@ -170,8 +170,9 @@ class EchoEngine:
                                        B, S, self._stream()), "echo_chain")
         return out, spec
 
-    def set_profiling(self, on: bool):
-        _lib.check(self.lib.echo_set_profiling(self._h, 1 if on else 0), "echo_set_profiling")
+    def set_profiling(self, slots: int):
+        """Arm HIP-event timing for the next ``slots`` chain calls (0 disarms)."""
+        _lib.check(self.lib.echo_set_profiling(self._h, int(slots)), "echo_set_profiling")
 
     def last_kernel_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

@@ -145,9 +145,11 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
                double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                int B, int n_streams, void* stream);
 
-/* Average device time in milliseconds of the kernels launched by the most recent echo_chain call on
- * this handle when profiling is enabled with echo_set_profiling(h, 1) (HIP events on the call's stream). */
-int echo_set_profiling(EchoHandle* h, int enable);
+/* Kernel timing with HIP events recorded on the call's own stream: echo_set_profiling(h, slots) arms the next
+ * `slots` echo_chain calls (0 disarms); echo_last_kernel_ms waits for them and returns the average device time
+ * in milliseconds of the IIR kernel, the band kernel and the fusion(+Kalman) kernels over the armed calls
+ * (first internal pass of each call), then re-arms from slot 0.  No counterpart in the reference. */
+int echo_set_profiling(EchoHandle* h, int slots);
 int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms);
 
 #ifdef __cplusplus
