@@ -7,49 +7,93 @@
 
 namespace echo {
 
+// Diagnostic build only (-DECHO_DIAG_STAMPS, `make diag`): thread 0 of the first blocks records the shader clock
+// after every phase into a buffer of its own.  The production library contains none of this.
+#ifdef ECHO_DIAG_STAMPS
+constexpr int kStampBlocks = 4096, kStampSlots = 24;
+__device__ unsigned long long g_stamps[kStampBlocks * kStampSlots];
+#define STAMP(k) do { if (tid == 0 && blk < kStampBlocks) g_stamps[blk * kStampSlots + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kNT) void band_kernel(BandParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
+    STAMP(0);
     ph_load(tid, kNT, blk, p, smem);
-    __syncthreads();
+    __syncthreads(); STAMP(1);
     ph_fir(tid, kNT, blk, p, smem);
-    __syncthreads();
+    __syncthreads(); STAMP(2);
     if (p.do_corr) {
         ph_corr(tid, kNT, blk, p, smem);
-        __syncthreads();
-        ph_reduce_a(tid, kNT, p, smem);
-        __syncthreads();
-        ph_reduce_b(tid, kNT, p, smem);
-        ph_rank(tid, kNT, p, smem);           // touches the noise window and two scalars only
-        __syncthreads();
+        __syncthreads(); STAMP(3);
+        ph_reduce(tid, kNT, p, smem);
+        ph_rank_count(tid, kNT, p, smem);     // reads the noise window, writes counts beyond the reduction scratch
+        __syncthreads(); STAMP(4);
+        ph_rank_pick(tid, kNT, p, smem);
+        __syncthreads(); STAMP(5);
         ph_finish(tid, kNT, blk, p, smem);
-    }
-    if (p.do_spec) {
-        __syncthreads();
-        ph_spec_load(tid, kNT, p, smem);
-        __syncthreads();
-        ph_fft_r8<false>(tid, kNT, 1024, p, smem);
-        __syncthreads();
-        ph_fft_r8<false>(tid, kNT, 128, p, smem);
-        __syncthreads();
-        ph_fft_r8<false>(tid, kNT, 16, p, smem);
-        __syncthreads();
-        ph_fft_mid(tid, kNT, p, smem);
-        __syncthreads();
-        ph_fft_r8<true>(tid, kNT, 16, p, smem);
-        __syncthreads();
-        ph_fft_r8<true>(tid, kNT, 128, p, smem);
-        __syncthreads();
-        ph_fft_r8<true>(tid, kNT, 1024, p, smem);
-        __syncthreads();
-        ph_spec_store(tid, kNT, blk, p, smem);
+        STAMP(6);
     }
 }
 
-int band_kernel_prepare(int smem_bytes) {
+// Spectrum: one workgroup per (frame, band); Bluestein rfft of the band signal in a 64-KB LDS buffer, two
+// workgroups per CU.  Data-independent table loads are issued one phase ahead of their use, in front of a barrier.
+__global__ __launch_bounds__(kNT, 4) void spec_kernel(BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    STAMP(7);
+    Tw3 tw = fft_tw_load(tid, 1024, p);
+    ph_spec_load(tid, kNT, blk, p, smem);
+    __syncthreads(); STAMP(8);
+    ph_fft_r8<false>(tid, 1024, p, smem, tw);
+    tw = fft_tw_load(tid, 128, p);
+    __syncthreads(); STAMP(9);
+    ph_fft_r8<false>(tid, 128, p, smem, tw);
+    tw = fft_tw_load(tid, 16, p);
+    __syncthreads(); STAMP(10);
+    ph_fft_r8<false>(tid, 16, p, smem, tw);
+    __syncthreads(); STAMP(11);
+    {
+        const Bh8 bh = fft_bh_load(tid, p);
+        ph_fft_mid(tid, p, smem, bh);
+    }
+    tw = fft_tw_load(tid, 16, p);
+    __syncthreads(); STAMP(12);
+    ph_fft_r8<true>(tid, 16, p, smem, tw);
+    tw = fft_tw_load(tid, 128, p);
+    __syncthreads(); STAMP(13);
+    ph_fft_r8<true>(tid, 128, p, smem, tw);
+    tw = fft_tw_load(tid, 1024, p);
+    __syncthreads(); STAMP(14);
+    ph_fft_r8<true>(tid, 1024, p, smem, tw);
+    __syncthreads(); STAMP(15);
+    ph_spec_store(tid, kNT, blk, p, smem);
+    STAMP(16);
+}
+
+#ifdef ECHO_DIAG_STAMPS
+extern "C" int echo_diag_read_stamps(unsigned long long* host, int n) {
+    if (n > kStampBlocks * kStampSlots) n = kStampBlocks * kStampSlots;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+extern "C" int echo_diag_stamp_shape(int* blocks, int* slots) { *blocks = kStampBlocks; *slots = kStampSlots; return 0; }
+#endif
+
+int band_kernel_prepare(int smem_bytes, int spec_smem_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, spec_smem_bytes);
     return e == hipSuccess ? 0 : -4;
+}
+
+int launch_spec(const BandParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(spec_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int launch_band(const BandParams& p, int B, hipStream_t s) {

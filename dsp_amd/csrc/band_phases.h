@@ -19,6 +19,18 @@
 #else
 #define ECHO_HD inline
 struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+#endif
+
+// Pointer to LDS data read one 8-byte element at a time.  On the device this is a volatile LDS-address-space
+// pointer: it stops the compiler from merging neighbouring reads into two-element reads, which run at half the
+// LDS rate on gfx950.  On the host it is a plain pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const volatile __attribute__((address_space(3))) double* lds_cptr_t;
+#define ECHO_LDS_CPTR(p) ((lds_cptr_t)(p))
+#else
+typedef const double* lds_cptr_t;
+#define ECHO_LDS_CPTR(p) (p)
 #endif
 
 namespace echo {
@@ -44,21 +56,24 @@ struct BandParams {
     int min_delay, noise_n, detector;
     int n2, nbins;
     int mode;
-    int do_corr, do_spec, spec_db;
+    int do_corr, spec_db;
     double snr_gate;
-    // padded coefficient tables (device global), zero-filled to a multiple of kR
+    // padded coefficient tables (device global), zero-filled to a multiple of kR plus one extra zero group
     int kgroups, mgroups;            // ceil(K/kR), ceil(M/kR)
-    const double* taps_rev;          // [nb][kgroups*kR]  taps reversed
-    const double* chirp;             // [nb][mgroups*kR]
-    const float2* bw;                // [n2]      exp(-i*pi*n^2/n2)
-    const float2* bhat;              // [kFftM]   FFT of the chirp filter, /kFftM, in pass order
-    const float2* tw;                // [kFftM]   exp(-2*pi*i*k/kFftM)
-    const float2* unpack;            // [n2+1]    exp(-2*pi*i*k/N)
+    const double* taps_rev;          // [nb][(kgroups+1)*kR]  taps reversed
+    const double* chirp;             // [nb][(mgroups+1)*kR]
+    const float2* bw;                // [n2 rounded up to even]  exp(-i*pi*n^2/n2)
+    const float2* bhat;              // [8][kFftM/16][2]  FFT of the chirp filter, /kFftM, pass order, lane-major
+    const float2* tw;                // radix-8 pass twiddles: for q in {1024,128,16}: [3][q] = W^i, W^2i, W^4i, W = exp(-2*pi*i/(8q))
+    const float2* post;              // [n2+1][2]  A[k] = w[k](1 - i u_k)/2, B[k] = conj(w[n2-k])(1 + i u_k)/2, u_k = exp(-2*pi*i*k/N)
+    int off_ctap, off_cchirp;        // LDS copies of this band's coefficient tables
     // LDS carve (byte offsets, 16-B aligned)
     int off_sig, sig_len;            // double[sig_len]: band_sig at [M-1, M-1+N), zeros elsewhere
-    int off_u;                       // union: double ybuf[ybuf_len] | float2 fft[kFftM] | reduction scratch
+    int off_u;                       // union: double ybuf[ybuf_len] | reduction scratch + median counts
+    int off_fft;                     // spectrum kernel: float2 fft[kFftM]
+    int spec_smem_bytes;
     int ybuf_len, ypad;              // ybuf holds input at [ypad, ypad+N)
-    int off_nw;                      // double[noise_n] noise window
+    int off_nw;                      // double[noise_n] noise window, then float[noise_n] (rounded copy)
     int off_misc;                    // small scalars
     int smem_bytes;
     // I/O (device global); any may be null depending on mode
@@ -67,6 +82,9 @@ struct BandParams {
     double* corr_io;                 // [B][nb][L]  in (MODE_CORR) / out (raw corr) / null
     double* band_out;                // [B][nb][N]
     float* spec_out;                 // [B][nb][nbins]
+    float* bandf_out;                // [B][nb][N] float32 copy of band_sig for the spectrum kernel (may be null)
+    const float* specf_in;           // spectrum kernel input, float32 [B][nb][N] (or null)
+    const double* specd_in;          // spectrum kernel input, float64 [B][nb][N] (or null)
     BandRes* res_out;                // [B][nb]
     int write_corr_mutated;          // MODE_CORR: write the zeroed blind zone back
 };
@@ -79,23 +97,37 @@ struct Misc {                        // lives at off_misc
 ECHO_HD double* lds_d(unsigned char* s, int off) { return reinterpret_cast<double*>(s + off); }
 ECHO_HD float2* lds_c(unsigned char* s, int off) { return reinterpret_cast<float2*>(s + off); }
 
-// out[r] = sum_j c[j] * in[r + j], r < kR, j < ngroups*kR; the window of kR inputs lives in registers
-// and rotates by static index, so each tap costs one LDS read per lane.
-ECHO_HD void sliding_dot(const double* in, const double* __restrict__ c, int ngroups, double (&acc)[kR]) {
-    double w[kR];
+// One group of kR taps: acc[r] += sum_t w[(r+t)%kR] * c[t]; slot t of the register window is refilled with the
+// sample kR positions ahead as soon as its last use is behind, so the window rotates by static index.
+ECHO_HD void dot_block(double (&w)[kR], const double (&c)[kR], const double* nx, double (&acc)[kR]) {
+    // volatile: keeps one 8-byte LDS read per element; merged two-element reads run at half the LDS rate on gfx950
+    lds_cptr_t vx = ECHO_LDS_CPTR(nx);
 #pragma unroll
-    for (int r = 0; r < kR; ++r) { w[r] = in[r]; acc[r] = 0.0; }
-    for (int g = 0; g < ngroups; ++g) {
-        const double* cg = c + g * kR;
-        const double* nx = in + (g + 1) * kR;
+    for (int t = 0; t < kR; ++t) {
 #pragma unroll
-        for (int t = 0; t < kR; ++t) {
-            const double ct = cg[t];
-#pragma unroll
-            for (int r = 0; r < kR; ++r) acc[r] = fma(w[(r + t) % kR], ct, acc[r]);
-            w[t] = nx[t];
-        }
+        for (int r = 0; r < kR; ++r) acc[r] = fma(w[(r + t) % kR], c[t], acc[r]);
+        w[t] = vx[t];
     }
+}
+
+// out[r] = sum_j c[j] * in[r + j], r < kR, j < ngroups*kR.  `in` and `c` are LDS arrays; c is padded with one
+// extra (zero) group so the coefficient prefetch never runs past it.  Coefficients for the next group are
+// fetched while the current group's kR*kR multiply-adds issue.
+ECHO_HD void sliding_dot(const double* in, const double* c, int ngroups, double (&acc)[kR]) {
+    double w[kR], c0[kR], c1[kR];
+    lds_cptr_t vc = ECHO_LDS_CPTR(c);
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { w[r] = in[r]; c0[r] = c[r]; acc[r] = 0.0; }
+    int g = 0;
+    for (; g + 1 < ngroups; g += 2) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c1[r] = vc[(g + 1) * kR + r];
+        dot_block(w, c0, in + (g + 1) * kR, acc);
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c0[r] = vc[(g + 2) * kR + r];
+        dot_block(w, c1, in + (g + 2) * kR, acc);
+    }
+    if (g < ngroups) dot_block(w, c0, in + (g + 1) * kR, acc);
 }
 
 // ---------------------------------------------------------------- phase 0: stage the input in LDS
@@ -103,22 +135,50 @@ ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned cha
     double* sig = lds_d(smem, p.off_sig);
     double* yb = lds_d(smem, p.off_u);
     const int band = blk % p.nb, frame = blk / p.nb;
-    (void)band;
+    // this band's coefficient tables -> LDS (read back as wave-uniform broadcasts by the sliding dots)
     if (p.mode == MODE_RX_FIR || p.mode == MODE_Y_FIR) {
-        for (int i = tid; i < p.ybuf_len; i += nt) {
-            const int n = i - p.ypad;
-            double v = 0.0;
-            if (n >= 0 && n < p.N)
-                v = (p.mode == MODE_RX_FIR) ? (double)p.rx_in[(size_t)frame * p.N + n]
-                                            : p.d_in[(size_t)blk * p.N + n];
-            yb[i] = v;
+        double* ct = lds_d(smem, p.off_ctap);
+        const int n = (p.kgroups + 1) * kR;
+        for (int i = tid; i < n; i += nt) ct[i] = p.taps_rev[(size_t)band * n + i];
+    }
+    if (p.do_corr && p.mode != MODE_CORR) {
+        double* cc = lds_d(smem, p.off_cchirp);
+        const int n = (p.mgroups + 1) * kR;
+        for (int i = tid; i < n; i += nt) cc[i] = p.chirp[(size_t)band * n + i];
+    }
+    if (p.mode == MODE_RX_FIR || p.mode == MODE_Y_FIR) {
+        // all global loads of a batch are issued before the first LDS store, so their latencies overlap
+        constexpr int kBatch = 5;
+        for (int i0 = tid; i0 < p.ybuf_len; i0 += kBatch * nt) {
+            double v[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int n = i0 + k * nt - p.ypad;
+                const int nc = n < 0 ? 0 : (n >= p.N ? p.N - 1 : n);
+                const double x = (p.mode == MODE_RX_FIR) ? (double)p.rx_in[(size_t)frame * p.N + nc]
+                                                         : p.d_in[(size_t)blk * p.N + nc];
+                v[k] = (n == nc) ? x : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+                if (i0 + k * nt < p.ybuf_len) yb[i0 + k * nt] = v[k];
         }
         for (int i = tid; i < p.sig_len; i += nt)
             if (i < p.M - 1 || i >= p.M - 1 + p.N) sig[i] = 0.0;
     } else if (p.mode == MODE_BAND) {
-        for (int i = tid; i < p.sig_len; i += nt) {
-            const int n = i - (p.M - 1);
-            sig[i] = (n >= 0 && n < p.N) ? p.d_in[(size_t)blk * p.N + n] : 0.0;
+        constexpr int kBatch = 5;
+        for (int i0 = tid; i0 < p.sig_len; i0 += kBatch * nt) {
+            double v[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int n = i0 + k * nt - (p.M - 1);
+                const int nc = n < 0 ? 0 : (n >= p.N ? p.N - 1 : n);
+                const double x = p.d_in[(size_t)blk * p.N + nc];
+                v[k] = (n == nc) ? x : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+                if (i0 + k * nt < p.sig_len) sig[i0 + k * nt] = v[k];
         }
     }
 }
@@ -129,19 +189,23 @@ ECHO_HD void ph_fir(int tid, int nt, int blk, const BandParams& p, unsigned char
     if (p.mode != MODE_RX_FIR && p.mode != MODE_Y_FIR) return;
     const double* yb = lds_d(smem, p.off_u);
     double* sig = lds_d(smem, p.off_sig);
-    const int band = blk % p.nb;
     const int n0 = tid * kR;
     if (n0 >= p.N) return;
     double acc[kR];
-    sliding_dot(yb + n0, p.taps_rev + (size_t)band * p.kgroups * kR, p.kgroups, acc);
+    sliding_dot(yb + n0, lds_d(smem, p.off_ctap), p.kgroups, acc);
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
         const int n = n0 + r;
         if (n < p.N) {
             sig[p.M - 1 + n] = acc[r];
             if (p.band_out) p.band_out[(size_t)blk * p.N + n] = acc[r];
+            if (p.bandf_out) p.bandf_out[(size_t)blk * p.N + n] = (float)acc[r];
         }
     }
+}
+
+ECHO_HD void combine(double& best, int& bidx, double b2, int i2) {
+    if (b2 > best || (b2 == best && i2 < bidx)) { best = b2; bidx = i2; }
 }
 
 // ---------------------------------------------------------------- phase 2: correlation + detector partials
@@ -152,9 +216,8 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
     if (!p.do_corr) return;
     const double* sig = lds_d(smem, p.off_sig);
     double* nw = lds_d(smem, p.off_nw);
-    double* red = lds_d(smem, p.off_u);            // [nt] best | [nt] amp | [nt] sumsq | int[nt] idx
-    int* redi = reinterpret_cast<int*>(red + 3 * nt);
-    const int band = blk % p.nb;
+    float* nwf = reinterpret_cast<float*>(nw + p.noise_n);
+    double* red = lds_d(smem, p.off_u);            // [slots] best | [slots] amp | [slots] sumsq | int[slots] idx
     const int k0 = tid * kR;
     double best = -INFINITY, amp = 0.0, sumsq = 0.0;
     int bidx = 0x7fffffff;
@@ -164,7 +227,7 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
 #pragma unroll
             for (int r = 0; r < kR; ++r) acc[r] = (k0 + r < p.L) ? p.corr_io[(size_t)blk * p.L + k0 + r] : 0.0;
         } else {
-            sliding_dot(sig + k0, p.chirp + (size_t)band * p.mgroups * kR, p.mgroups, acc);
+            sliding_dot(sig + k0, lds_d(smem, p.off_cchirp), p.mgroups, acc);
             if (p.corr_io) {
 #pragma unroll
                 for (int r = 0; r < kR; ++r)
@@ -187,65 +250,105 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
                 if (v > best) { best = v; bidx = q; }
                 if (p.detector == 0) {
                     const int w = q - p.min_delay;
-                    if (w >= 0 && w < p.noise_n) nw[w] = av;
+                    if (w >= 0 && w < p.noise_n) { nw[w] = av; nwf[w] = (float)av; }
                 } else if (p.detector == 2) {
                     if (q < p.noise_n) sumsq += v * v;
                 }
             }
         }
     }
-    red[tid] = best; red[nt + tid] = amp; red[2 * nt + tid] = sumsq; redi[tid] = bidx;
-}
-
-ECHO_HD void combine(double& best, int& bidx, double b2, int i2) {
-    if (b2 > best || (b2 == best && i2 < bidx)) { best = b2; bidx = i2; }
-}
-
-// phase 3a: 64 threads fold nt partials to 64; phase 3b: thread 0 folds 64 to 1.
-ECHO_HD void ph_reduce_a(int tid, int nt, const BandParams& p, unsigned char* smem) {
-    if (!p.do_corr || tid >= 64) return;
-    double* red = lds_d(smem, p.off_u);
-    int* redi = reinterpret_cast<int*>(red + 3 * nt);
-    double best = red[tid], amp = red[nt + tid], ss = red[2 * nt + tid];
-    int bidx = redi[tid];
-    for (int j = tid + 64; j < nt; j += 64) {
-        combine(best, bidx, red[j], redi[j]);
-        amp = red[nt + j] > amp ? red[nt + j] : amp;
-        ss += red[2 * nt + j];
+    // one partial per wavefront on the device (butterfly over the 64 lanes), one per thread on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double b2 = __shfl_xor(best, o); const int i2 = __shfl_xor(bidx, o);
+        combine(best, bidx, b2, i2);
+        const double a2 = __shfl_xor(amp, o); amp = a2 > amp ? a2 : amp;
+        sumsq += __shfl_xor(sumsq, o);
     }
-    red[tid] = best; red[nt + tid] = amp; red[2 * nt + tid] = ss; redi[tid] = bidx;
+    const int slots = nt / 64, slot = tid / 64;
+    const bool writer = (tid & 63) == 0;
+#else
+    const int slots = nt, slot = tid;
+    const bool writer = true;
+#endif
+    if (writer) {
+        int* redi = reinterpret_cast<int*>(red + 3 * slots);
+        red[slot] = best; red[slots + slot] = amp; red[2 * slots + slot] = sumsq; redi[slot] = bidx;
+    }
 }
 
-ECHO_HD void ph_reduce_b(int tid, int nt, const BandParams& p, unsigned char* smem) {
+// phase 3: thread 0 folds the per-wavefront partials
+ECHO_HD void ph_reduce(int tid, int nt, const BandParams& p, unsigned char* smem) {
     if (!p.do_corr || tid != 0) return;
-    double* red = lds_d(smem, p.off_u);
-    int* redi = reinterpret_cast<int*>(red + 3 * nt);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int slots = nt / 64;
+#else
+    const int slots = nt;
+#endif
+    const double* red = lds_d(smem, p.off_u);
+    const int* redi = reinterpret_cast<const int*>(red + 3 * slots);
     Misc* m = reinterpret_cast<Misc*>(smem + p.off_misc);
-    double best = red[0], amp = red[nt], ss = red[2 * nt];
+    double best = red[0], amp = red[slots], ss = red[2 * slots];
     int bidx = redi[0];
-    for (int j = 1; j < 64 && j < nt; ++j) {
+    for (int j = 1; j < slots; ++j) {
         combine(best, bidx, red[j], redi[j]);
-        amp = red[nt + j] > amp ? red[nt + j] : amp;
-        ss += red[2 * nt + j];
+        amp = red[slots + j] > amp ? red[slots + j] : amp;
+        ss += red[2 * slots + j];
     }
     m->best = best; m->bidx = bidx; m->amp = amp; m->sumsq = ss;
 }
 
-// phase 4: median of the noise window by rank counting (np.median: mean of the two middle order statistics)
-ECHO_HD void ph_rank(int tid, int nt, const BandParams& p, unsigned char* smem) {
+// phase 4: median of the noise window (np.median: mean of the two middle order statistics) by counting.
+// Element v is the k-th order statistic iff #(u < v) <= k < #(u < v) + #(u == v).  Counting runs on the float-rounded
+// copy (rounding is monotonic, so a strict float inequality decides the float64 one); an element whose float value
+// is shared with another is recounted in float64 when its float rank interval contains a wanted rank.  The count
+// loop is split over nt / n thread groups whose partial counts meet in LDS (after the reduction scratch).
+ECHO_HD int rank_parts(int nt, int n) { int parts = n > 0 ? nt / n : 1; return parts < 1 ? 1 : (parts > 4 ? 4 : parts); }
+
+ECHO_HD void ph_rank_count(int tid, int nt, const BandParams& p, unsigned char* smem) {
+    if (!p.do_corr || p.detector != 0) return;
+    const int n = p.noise_n;
+    if (n <= 0) return;
+    const float* nwf = reinterpret_cast<const float*>(lds_d(smem, p.off_nw) + n);
+    int* cnt = reinterpret_cast<int*>(lds_d(smem, p.off_u) + 4 * nt);   // [parts][n][2]
+    const int parts = rank_parts(nt, n);
+    const int chunk = (n + parts - 1) / parts;
+    for (int t = tid; t < parts * n; t += nt) {
+        const int i = t % n, part = t / n;
+        const int j0 = part * chunk, j1 = (j0 + chunk < n) ? j0 + chunk : n;
+        const float v = nwf[i];
+        int less = 0, eq = 0;
+#pragma unroll 8
+        for (int j = j0; j < j1; ++j) {
+            const float u = nwf[j];
+            less += (u < v) ? 1 : 0;
+            eq += (u == v) ? 1 : 0;
+        }
+        cnt[(part * n + i) * 2] = less; cnt[(part * n + i) * 2 + 1] = eq;
+    }
+}
+
+ECHO_HD void ph_rank_pick(int tid, int nt, const BandParams& p, unsigned char* smem) {
     if (!p.do_corr || p.detector != 0) return;
     const double* nw = lds_d(smem, p.off_nw);
+    const int* cnt = reinterpret_cast<const int*>(lds_d(smem, p.off_u) + 4 * nt);
     Misc* m = reinterpret_cast<Misc*>(smem + p.off_misc);
     const int n = p.noise_n;
+    if (n <= 0) { if (tid == 0) { m->med0 = 0.0; m->med1 = 0.0; } return; }
+    const int parts = rank_parts(nt, n);
+    const int k0 = (n - 1) / 2, k1 = n / 2;
     for (int i = tid; i < n; i += nt) {
+        int less = 0, eq = 0;
+        for (int part = 0; part < parts; ++part) { less += cnt[(part * n + i) * 2]; eq += cnt[(part * n + i) * 2 + 1]; }
+        if (k1 < less || k0 >= less + eq) continue;          // neither wanted rank inside this element's interval
         const double v = nw[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double u = nw[j];
-            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        if (eq > 1) {                                         // float tie: exact recount
+            less = 0; eq = 0;
+            for (int j = 0; j < n; ++j) { const double u = nw[j]; less += (u < v) ? 1 : 0; eq += (u == v) ? 1 : 0; }
         }
-        if (rank == (n - 1) / 2) m->med0 = v;
-        if (rank == n / 2) m->med1 = v;
+        if (less <= k0 && k0 < less + eq) m->med0 = v;
+        if (less <= k1 && k1 < less + eq) m->med1 = v;
     }
 }
 
@@ -269,12 +372,13 @@ ECHO_HD void ph_finish(int tid, int nt, int blk, const BandParams& p, unsigned c
 }
 
 // ---------------------------------------------------------------- spectrum: FFT building blocks
-ECHO_HD float2 cmul(float2 a, float2 b) { float2 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
-ECHO_HD float2 cmulc(float2 a, float2 b) { float2 r; r.x = a.x * b.x + a.y * b.y; r.y = a.y * b.x - a.x * b.y; return r; }  // a*conj(b)
-ECHO_HD float2 cadd(float2 a, float2 b) { float2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
-ECHO_HD float2 csub(float2 a, float2 b) { float2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+ECHO_HD float2 mk2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+ECHO_HD float2 cmul(float2 a, float2 b) { return mk2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+ECHO_HD float2 cmulc(float2 a, float2 b) { return mk2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+ECHO_HD float2 cadd(float2 a, float2 b) { return mk2(a.x + b.x, a.y + b.y); }
+ECHO_HD float2 csub(float2 a, float2 b) { return mk2(a.x - b.x, a.y - b.y); }
 template <bool INV> ECHO_HD float2 mul_mi(float2 a) {   // forward: a * (-i); inverse: a * (+i)
-    float2 r; if (!INV) { r.x = a.y; r.y = -a.x; } else { r.x = -a.y; r.y = a.x; } return r;
+    return INV ? mk2(-a.y, a.x) : mk2(a.y, -a.x);
 }
 
 template <bool INV> ECHO_HD void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
@@ -286,118 +390,179 @@ template <bool INV> ECHO_HD void dft8(float2 (&v)[8]) {
     const float h = 0.70710678118654752440f;
     float2 a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
     float2 b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
-    float2 t;
-    if (!INV) { t.x = h * (b1.x + b1.y); t.y = h * (b1.y - b1.x); b1 = t;
+    if (!INV) { b1 = mk2(h * (b1.x + b1.y), h * (b1.y - b1.x));
                 b2 = mul_mi<false>(b2);
-                t.x = h * (b3.y - b3.x); t.y = -h * (b3.x + b3.y); b3 = t; }
-    else      { t.x = h * (b1.x - b1.y); t.y = h * (b1.y + b1.x); b1 = t;
+                b3 = mk2(h * (b3.y - b3.x), -h * (b3.x + b3.y)); }
+    else      { b1 = mk2(h * (b1.x - b1.y), h * (b1.y + b1.x));
                 b2 = mul_mi<true>(b2);
-                t.x = -h * (b3.x + b3.y); t.y = h * (b3.x - b3.y); b3 = t; }
+                b3 = mk2(-h * (b3.x + b3.y), h * (b3.x - b3.y)); }
     dft4<INV>(a0, a1, a2, a3);
     dft4<INV>(b0, b1, b2, b3);
     v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
     v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
 }
 
-// LDS address of FFT element i (hook for bank-conflict padding)
-ECHO_HD int fa(int i) { return i; }
+// LDS position of FFT element i.  Bits 1..4 of the index are XORed with bits of i>>5 so that every access pattern
+// of the transform is bank-conflict free: 32 consecutive elements (strided passes), 16 elements of two adjacent
+// 128-blocks (q = 16 pass) and 16 contiguous elements per lane (middle pass).  Bit 0 is untouched, so an even
+// element and its successor stay adjacent and can move as one 16-byte access.
+ECHO_HD int fa(int i) {
+    const int h = i >> 5;
+    return i ^ (((h & 7) << 1) | (((h >> 2) & 1) << 4));
+}
+ECHO_HD float4 ld4(const float2* f, int e) { return *reinterpret_cast<const float4*>(f + e); }
+ECHO_HD void st4(float2* f, int e, float2 a, float2 b) {
+    float4 v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; *reinterpret_cast<float4*>(f + e) = v;
+}
 
-// Bluestein input: a[n] = (x[2n] + i x[2n+1]) * w[n], zero-padded to kFftM
-ECHO_HD void ph_spec_load(int tid, int nt, const BandParams& p, unsigned char* smem) {
-    if (!p.do_spec) return;
-    const double* sig = lds_d(smem, p.off_sig) + (p.M - 1);
-    float2* f = lds_c(smem, p.off_u);
-    for (int n = tid; n < kFftM; n += nt) {
-        float2 a; a.x = 0.f; a.y = 0.f;
+// Bluestein input: a[n] = (x[2n] + i x[2n+1]) * w[n], zero-padded to kFftM; two elements per lane, x read
+// straight from global memory (float32 copy written by the band kernel, or float64 band_sig)
+ECHO_HD void ph_spec_load(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    float2* f = lds_c(smem, p.off_fft);
+    for (int n = 2 * tid; n < kFftM; n += 2 * nt) {
+        float2 a0 = mk2(0.f, 0.f), a1 = mk2(0.f, 0.f);
         if (n < p.n2) {
-            float2 z; z.x = (float)sig[2 * n]; z.y = (float)sig[2 * n + 1];
-            a = cmul(z, p.bw[n]);
+            const float4 w = ld4(p.bw, n);
+            const bool two = n + 1 < p.n2;
+            float2 x0, x1 = mk2(0.f, 0.f);
+            if (p.specf_in) {
+                const float2* x = reinterpret_cast<const float2*>(p.specf_in + (size_t)blk * p.N) + n;
+                x0 = x[0]; if (two) x1 = x[1];
+            } else {
+                const double* x = p.specd_in + (size_t)blk * p.N + 2 * n;
+                x0 = mk2((float)x[0], (float)x[1]); if (two) x1 = mk2((float)x[2], (float)x[3]);
+            }
+            a0 = cmul(x0, mk2(w.x, w.y));
+            if (two) a1 = cmul(x1, mk2(w.z, w.w));
         }
-        f[fa(n)] = a;
+        st4(f, fa(n), a0, a1);
     }
 }
 
-// One radix-8 pass over sub-FFTs of size 8q.  Forward (decimation in frequency): butterfly then twiddle;
-// inverse (its conjugate transpose): conjugate twiddle then butterfly.
-template <bool INV> ECHO_HD void ph_fft_r8(int tid, int nt, int q, const BandParams& p, unsigned char* smem) {
-    if (!p.do_spec) return;
-    float2* f = lds_c(smem, p.off_u);
-    const int tstep = kFftM / (8 * q);
-    for (int u = tid; u < kFftM / 8; u += nt) {
-        const int i = u % q, base = (u / q) * 8 * q + i;
-        float2 v[8];
+// Radix-8 butterfly with twiddles W^m, m = 1..7, built from W, W^2, W^4.
+// Forward (decimation in frequency): butterfly then twiddle; inverse (its conjugate transpose): conjugate
+// twiddle then butterfly.
+template <bool INV> ECHO_HD void bfly8(float2 (&v)[8], float2 w1, float2 w2, float2 w4) {
+    const float2 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+    if (INV) {
+        v[1] = cmulc(v[1], w1); v[2] = cmulc(v[2], w2); v[3] = cmulc(v[3], w3); v[4] = cmulc(v[4], w4);
+        v[5] = cmulc(v[5], w5); v[6] = cmulc(v[6], w6); v[7] = cmulc(v[7], w7);
+    }
+    dft8<INV>(v);
+    if (!INV) {
+        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+    }
+}
+
+ECHO_HD int tw_offset(int q) { return q == 1024 ? 0 : (q == 128 ? 3 * 1024 : 3 * 1024 + 3 * 128); }
+
+// Twiddles of one radix-8 pass for the two butterflies a thread owns.  They do not depend on the data, so the
+// kernel loads them one phase ahead of their use and the global-load latency hides behind the barrier.
+struct Tw3 { float4 w1, w2, w4; };
+ECHO_HD Tw3 fft_tw_load(int tid, int q, const BandParams& p) {
+    const float2* t1 = p.tw + tw_offset(q);
+    const int i = 2 * (tid % (q >> 1));
+    Tw3 t; t.w1 = ld4(t1, i); t.w2 = ld4(t1 + q, i); t.w4 = ld4(t1 + 2 * q, i);
+    return t;
+}
+
+// One radix-8 pass over sub-FFTs of size 8q; each of the kFftM/16 threads owns butterflies i and i+1 of one
+// sub-FFT, so every LDS access moves two adjacent elements (16 bytes).
+template <bool INV> ECHO_HD void ph_fft_r8(int tid, int q, const BandParams& p, unsigned char* smem, const Tw3& t) {
+    if (tid >= kFftM / 16) return;
+    float2* f = lds_c(smem, p.off_fft);
+    const int hq = q >> 1;
+    const int i = 2 * (tid % hq), base = (tid / hq) * 8 * q + i;
+    float2 va[8], vb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f[fa(base + j * q)];
-        if (INV) {
+    for (int j = 0; j < 8; ++j) {
+        const float4 x = ld4(f, fa(base + j * q));
+        va[j] = mk2(x.x, x.y); vb[j] = mk2(x.z, x.w);
+    }
+    bfly8<INV>(va, mk2(t.w1.x, t.w1.y), mk2(t.w2.x, t.w2.y), mk2(t.w4.x, t.w4.y));
+    bfly8<INV>(vb, mk2(t.w1.z, t.w1.w), mk2(t.w2.z, t.w2.w), mk2(t.w4.z, t.w4.w));
 #pragma unroll
-            for (int m = 1; m < 8; ++m) v[m] = cmulc(v[m], p.tw[i * m * tstep]);
-        }
-        dft8<INV>(v);
-        if (!INV) {
-#pragma unroll
-            for (int m = 1; m < 8; ++m) v[m] = cmul(v[m], p.tw[i * m * tstep]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[fa(base + j * q)] = v[j];
+    for (int j = 0; j < 8; ++j) st4(f, fa(base + j * q), va[j], vb[j]);
+}
+
+// exp(-2*pi*i*k/16) for the k = i*m products of the in-register radix-4 stage
+ECHO_HD float2 w16(int k) {
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    switch (k) {
+        case 1: return mk2(c1, -s1);
+        case 2: return mk2(h, -h);
+        case 3: return mk2(s1, -c1);
+        case 4: return mk2(0.f, -1.f);
+        case 6: return mk2(-h, -h);
+        case 9: return mk2(-c1, s1);
+        default: return mk2(1.f, 0.f);
     }
 }
 
 // Middle of the transform, per contiguous 16 elements, all in registers:
 // forward radix-4 (q=4) and radix-4 (q=1), multiply by the chirp-filter spectrum, inverse radix-4 (q=1) and (q=4).
-ECHO_HD void ph_fft_mid(int tid, int nt, const BandParams& p, unsigned char* smem) {
-    if (!p.do_spec) return;
-    float2* f = lds_c(smem, p.off_u);
-    const int ts = kFftM / 16;
-    for (int u = tid; u < kFftM / 16; u += nt) {
-        const int base = u * 16;
+struct Bh8 { float4 v[8]; };
+ECHO_HD Bh8 fft_bh_load(int tid, const BandParams& p) {
+    Bh8 b;
+    const int nu = kFftM / 16, u = tid < nu ? tid : 0;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) b.v[jj] = ld4(p.bhat, 2 * (jj * nu + u));
+    return b;
+}
+
+ECHO_HD void ph_fft_mid(int tid, const BandParams& p, unsigned char* smem, const Bh8& bh8) {
+    if (tid >= kFftM / 16) return;
+    float2* f = lds_c(smem, p.off_fft);
+    {
+        const int u = tid;
+        const int e0 = 16 * u, hi = e0 & ~31, lo = e0 & 31, g = fa(e0) ^ e0;
         float2 v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = f[fa(base + j)];
-        // forward, q = 4: butterflies over (i, i+4, i+8, i+12), twiddle W16^(i*m)
+        for (int jj = 0; jj < 8; ++jj) {
+            const float4 x = ld4(f, hi | ((lo + 2 * jj) ^ g));
+            v[2 * jj] = mk2(x.x, x.y); v[2 * jj + 1] = mk2(x.z, x.w);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {          // forward, q = 4: (i, i+4, i+8, i+12), twiddle W16^(i*m)
             dft4<false>(v[i], v[i + 4], v[i + 8], v[i + 12]);
 #pragma unroll
             for (int m = 1; m < 4; ++m)
-                if (i) v[i + 4 * m] = cmul(v[i + 4 * m], p.tw[i * m * ts]);
+                if (i) v[i + 4 * m] = cmul(v[i + 4 * m], w16(i * m));
         }
-        // forward, q = 1
 #pragma unroll
-        for (int b = 0; b < 4; ++b) dft4<false>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
-        // pointwise product with the (pass-ordered, 1/M-scaled) chirp-filter spectrum
+        for (int b = 0; b < 4; ++b) dft4<false>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);   // q = 1
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = cmul(v[j], p.bhat[base + j]);
-        // inverse, q = 1
+        for (int jj = 0; jj < 8; ++jj) {       // pointwise product with the chirp-filter spectrum
+            const float4 bh = bh8.v[jj];
+            v[2 * jj] = cmul(v[2 * jj], mk2(bh.x, bh.y));
+            v[2 * jj + 1] = cmul(v[2 * jj + 1], mk2(bh.z, bh.w));
+        }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) dft4<true>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
-        // inverse, q = 4
+        for (int b = 0; b < 4; ++b) dft4<true>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);    // inverse q = 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {          // inverse, q = 4
 #pragma unroll
             for (int m = 1; m < 4; ++m)
-                if (i) v[i + 4 * m] = cmulc(v[i + 4 * m], p.tw[i * m * ts]);
+                if (i) v[i + 4 * m] = cmulc(v[i + 4 * m], w16(i * m));
             dft4<true>(v[i], v[i + 4], v[i + 8], v[i + 12]);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) f[fa(base + j)] = v[j];
+        for (int jj = 0; jj < 8; ++jj) st4(f, hi | ((lo + 2 * jj) ^ g), v[2 * jj], v[2 * jj + 1]);
     }
 }
 
-// Z[k] = c[k] * w[k]; X[k] = E + u[k] * (-i) * O with E,O = (Z[k] +- conj(Z[n2-k]))/2; magnitude (dB)
+// X[k] = c[k] * A[k] + conj(c[n2-k]) * B[k]: the Bluestein post-multiply and the real-FFT unpacking folded into
+// one table (Z[k] = c[k] w[k]; X[k] = (Z[k] + conj Z[n2-k])/2 - i u_k (Z[k] - conj Z[n2-k])/2); magnitude (dB)
 ECHO_HD void ph_spec_store(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
-    if (!p.do_spec) return;
-    const float2* f = lds_c(smem, p.off_u);
+    const float2* f = lds_c(smem, p.off_fft);
     for (int k = tid; k < p.nbins; k += nt) {
         const int ka = (k == p.n2) ? 0 : k;
         const int kb = (k == 0 || k == p.n2) ? 0 : p.n2 - k;
-        const float2 za = cmul(f[fa(ka)], p.bw[ka]);
-        float2 zb = cmul(f[fa(kb)], p.bw[kb]);
-        zb.y = -zb.y;
-        float2 e, o;
-        e.x = 0.5f * (za.x + zb.x); e.y = 0.5f * (za.y + zb.y);
-        o.x = 0.5f * (za.x - zb.x); o.y = 0.5f * (za.y - zb.y);
-        float2 mo; mo.x = o.y; mo.y = -o.x;                      // -i * O
-        const float2 x = cadd(e, cmul(p.unpack[k], mo));
+        const float4 ab = ld4(p.post, 2 * k);
+        const float2 ca = f[fa(ka)];
+        float2 cb = f[fa(kb)]; cb.y = -cb.y;
+        const float2 x = cadd(cmul(ca, mk2(ab.x, ab.y)), cmul(cb, mk2(ab.z, ab.w)));
         float mag = sqrtf(x.x * x.x + x.y * x.y);
         if (p.spec_db) mag = 20.0f * log10f(fmaxf(mag, 1e-12f));
         p.spec_out[(size_t)blk * p.nbins + k] = mag;

@@ -19,11 +19,12 @@ struct EchoHandle {
     BandParams base;                       // sizes, layout and device table pointers
     // device constant tables
     double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
-    float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_unpack = nullptr;
+    float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
     double* d_fwd = nullptr;               // IIR forward-pass output
     double* d_y = nullptr;                 // IIR result
+    float* d_bandf = nullptr;              // float32 band_sig handed from the band kernel to the spectrum kernel
     BandRes* d_res = nullptr;
     double* d_fused = nullptr;
     uint8_t* d_vany = nullptr;
@@ -44,7 +45,8 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
-    (void)hipFree(h->d_vany);
+    (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf);
+    h->d_bandf = nullptr;
     h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
     h->cap_frames = 0;
 }
@@ -59,6 +61,7 @@ int ensure_scratch(EchoHandle* h, int frames) {
     const size_t y_n = (size_t)frames * c.n_bands * c.n_rx;
     if (hipMalloc(reinterpret_cast<void**>(&h->d_fwd), fwd_n * sizeof(double)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_y), y_n * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_vany), (size_t)frames) != hipSuccess) {
@@ -73,6 +76,7 @@ IirParams iir_params(EchoHandle* h, const float* rx, double* y, int B) {
     IirParams p;
     p.rx = rx; p.y = y; p.fwd = h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands; p.ntiles = (B + 63) / 64;
+    p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     return p;
 }
 
@@ -144,11 +148,11 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     up(dev_upload(&h->d_bw, t.bw.data(), t.bw.size()));
     up(dev_upload(&h->d_bhat, t.bhat.data(), t.bhat.size()));
     up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
-    up(dev_upload(&h->d_unpack, t.unpack.data(), t.unpack.size()));
-    if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes);
+    up(dev_upload(&h->d_post, t.post.data(), t.post.size()));
+    if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
     if (rc != ECHO_OK) { echo_destroy(h); return rc; }
     h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
-    h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.unpack = h->d_unpack;
+    h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
     *out = h;
@@ -158,7 +162,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
 void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
-    void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_unpack};
+    void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -204,7 +208,7 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fus
 int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream) {
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     BandParams p = h->base;
-    p.mode = MODE_RX_FIR; p.do_corr = 0; p.do_spec = 0; p.rx_in = rx; p.band_out = out;
+    p.mode = MODE_RX_FIR; p.do_corr = 0; p.rx_in = rx; p.band_out = out;
     return launch_band(p, B, static_cast<hipStream_t>(stream));
 }
 
@@ -219,7 +223,7 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
         rc = launch_iir(iir_params(h, rx + (size_t)f0 * h->cfg.n_rx, h->d_y, n), h->cfg.iir_ncoef, h->bodd0, s);
         if (rc) return rc;
         BandParams p = h->base;
-        p.mode = MODE_Y_FIR; p.do_corr = 0; p.do_spec = 0; p.d_in = h->d_y; p.band_out = band_sig + o;
+        p.mode = MODE_Y_FIR; p.do_corr = 0; p.d_in = h->d_y; p.band_out = band_sig + o;
         rc = launch_band(p, n, s);
         if (rc) return rc;
     }
@@ -229,8 +233,8 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
     if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
     BandParams p = h->base;
-    p.mode = MODE_BAND; p.do_corr = 0; p.do_spec = 1; p.spec_db = db ? 1 : 0; p.d_in = band_sig; p.spec_out = spec;
-    return launch_band(p, B, static_cast<hipStream_t>(stream));
+    p.spec_db = db ? 1 : 0; p.specd_in = band_sig; p.spec_out = spec;
+    return launch_spec(p, B, static_cast<hipStream_t>(stream));
 }
 
 int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
@@ -241,7 +245,7 @@ int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
 int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream) {
     if (!h || !band_sig || !corr || B < 0) return ECHO_ERR_INVALID;
     BandParams p = h->base;
-    p.mode = MODE_BAND; p.do_corr = 1; p.do_spec = 0; p.d_in = band_sig; p.corr_io = corr; p.res_out = nullptr;
+    p.mode = MODE_BAND; p.do_corr = 1; p.d_in = band_sig; p.corr_io = corr; p.res_out = nullptr;
     return launch_band(p, B, static_cast<hipStream_t>(stream));
 }
 
@@ -256,7 +260,7 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
         BandParams p = h->base;
-        p.mode = MODE_CORR; p.do_corr = 1; p.do_spec = 0; p.write_corr_mutated = 1;
+        p.mode = MODE_CORR; p.do_corr = 1; p.write_corr_mutated = 1;
         p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->d_res;
         rc = launch_band(p, n, s);
         if (rc) return rc;
@@ -325,11 +329,17 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         if (rc) return rc;
         if (prof) (void)hipEventRecord(ev[1], s);
         BandParams p = h->base;
-        p.mode = MODE_Y_FIR; p.do_corr = 1; p.do_spec = spec_db ? 1 : 0; p.spec_db = 1;
+        p.mode = MODE_Y_FIR; p.do_corr = 1;
         p.d_in = h->d_y; p.res_out = h->d_res;
-        p.spec_out = spec_db ? spec_db + (size_t)f0 * nb * p.nbins : nullptr;
+        p.bandf_out = spec_db ? h->d_bandf : nullptr;
         rc = launch_band(p, n, s);
         if (rc) return rc;
+        if (spec_db) {
+            BandParams q = h->base;
+            q.spec_db = 1; q.specf_in = h->d_bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
+            rc = launch_spec(q, n, s);
+            if (rc) return rc;
+        }
         if (prof) (void)hipEventRecord(ev[2], s);
         rc = launch_fuse(fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n), s);
         if (rc) return rc;

@@ -15,6 +15,7 @@ struct IirParams {
     const double* a;      // [nb][NC]
     const double* zi;     // [nb][NC-1]
     int B, N, P, nb, ntiles;
+    int y_aligned16;      // y base and every row start are 16-byte aligned (N even): 16-byte stores allowed
 };
 
 struct FuseParams {
@@ -38,7 +39,8 @@ struct KalmanParams {
 
 int launch_iir(const IirParams& p, int ncoef, bool bodd0, hipStream_t s);
 int launch_band(const BandParams& p, int B, hipStream_t s);
-int band_kernel_prepare(int smem_bytes);
+int band_kernel_prepare(int smem_bytes, int spec_smem_bytes);
+int launch_spec(const BandParams& p, int B, hipStream_t s);
 int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, BandRes* res, int n, hipStream_t s);
 int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s);
 int launch_fuse(const FuseParams& p, hipStream_t s);

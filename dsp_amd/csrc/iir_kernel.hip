@@ -45,15 +45,14 @@ struct Df2t {
     }
 };
 
-constexpr int XS = 65;      // LDS row stride (floats) of the rx tile: 64 samples + 1 pad
-constexpr int YS = 33;      // LDS row stride (doubles) of the output tile: 32 samples + 1 pad
+constexpr int XS = 68;      // LDS row stride (floats) of the rx tile: 64 samples + 4 pad (16-B aligned rows, conflict-free b128)
+constexpr int YS = 34;      // LDS row stride (doubles) of the output tile: 32 samples + 2 pad (16-B aligned rows)
 constexpr int CH = 32;      // samples per streamed chunk
-constexpr int PF = 16;      // backward-pass prefetch depth (samples)
 
 template <int NC, bool BODD0>
 __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
-    __shared__ float xt[2][64 * XS];
-    __shared__ double yt[64 * YS];
+    __shared__ __attribute__((aligned(16))) float xt[2][64 * XS];
+    __shared__ __attribute__((aligned(16))) double yt[64 * YS];
     const int lane = threadIdx.x;
     // blocks id, id+8, id+16 (same XCD under round-robin placement) are the bands of one frame tile,
     // so the three reads of an rx tile meet in one L2
@@ -69,61 +68,75 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
     for (int k = 0; k < NC; ++k) { b[k] = p.b[band * NC + k]; a[k] = p.a[band * NC + k]; }
     const double* zi = p.zi + band * (NC - 1);
 
-    // cooperative load of columns [c0, c0+ncol) of the tile's 64 rows into registers (ncol = 32 or 64)
-    auto row_ptr = [&](int r) { int f = f0 + r; if (f >= p.B) f = p.B - 1; return p.rx + (size_t)f * N; };
+    // Cooperative, branch-free load of columns [c0, c0+32) of the tile's 64 rows: lane -> (row it*2 + lane/32,
+    // column lane%32), one 128-B row segment per half wave.  Columns past the frame end are clamped (their values
+    // are never consumed); rows past the batch end repeat the last frame.
+    const int lrow = lane >> 5, lcol = lane & 31;
     float pre[CH];
-    auto load_chunk = [&](int c0) {          // 32 columns: lane -> (row = it*2 + lane/32, col = lane%32)
+    auto load_chunk = [&](int c0) {
+        int c = c0 + lcol;
+        c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
 #pragma unroll
         for (int it = 0; it < CH; ++it) {
-            const int r = it * 2 + (lane >> 5), c = c0 + (lane & 31);
-            pre[it] = (c >= 0 && c < N) ? row_ptr(r)[c] : 0.f;
+            int f = f0 + it * 2 + lrow;
+            f = f < p.B ? f : p.B - 1;
+            pre[it] = p.rx[(size_t)f * N + c];
         }
     };
     auto store_chunk = [&](float* dst, int colofs) {
 #pragma unroll
-        for (int it = 0; it < CH; ++it) {
-            const int r = it * 2 + (lane >> 5), c = lane & 31;
-            dst[r * XS + colofs + c] = pre[it];
-        }
+        for (int it = 0; it < CH; ++it) dst[(it * 2 + lrow) * XS + colofs + lcol] = pre[it];
     };
 
     double* fwd = p.fwd + ((size_t)(band * p.ntiles + tile) * NE) * 64 + lane;
     Df2t<NC, BODD0> f;
+    // Only the two 32-step blocks below are unrolled; everything else stays a rolled loop so the hot code
+    // (about 20 KB) fits the instruction cache.
 
     // ---- forward pass: left odd extension from x[0..P]
     load_chunk(0);  store_chunk(xt[0], 0);
     load_chunk(CH); store_chunk(xt[0], CH);
     __syncthreads();
     const float* xr = xt[0] + lane * XS;
-    const float x0 = xr[0];
-    int i = 0;
     {
-        const float e0 = 2.0f * x0 - xr[P];
-        f.init(zi, (double)e0);
-    }
-    for (int k = 0; k < P; ++k, ++i) {
-        const float e = 2.0f * x0 - xr[P - k];
-        fwd[(size_t)i * 64] = f.step((double)e, b, a);
+        const float x0 = xr[0];
+        f.init(zi, (double)(2.0f * x0 - xr[P]));
+#pragma unroll 1
+        for (int k = 0; k < P; ++k) {
+            const float e = 2.0f * x0 - xr[P - k];
+            *fwd = f.step((double)e, b, a);
+            fwd += 64;
+        }
     }
     __syncthreads();
-    // ---- forward pass: the frame itself, 32-sample chunks, next chunk prefetched into registers
-    const int nchunks = (N + CH - 1) / CH;
+    // ---- forward pass: the frame itself, 32-sample chunks held in registers, next chunk prefetched
+    const int nfull = N / CH, ntail = N - nfull * CH;
     load_chunk(0); store_chunk(xt[0], 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll 1
+    for (int c = 0; c < nfull; ++c) {
         const int cur = c & 1;
-        if (c + 1 < nchunks) load_chunk((c + 1) * CH);
-        const float* xc = xt[cur] + lane * XS;
-        const int cnt = (N - c * CH) < CH ? (N - c * CH) : CH;
-        if (cnt == CH) {
-#pragma unroll 4
-            for (int t = 0; t < CH; ++t, ++i) fwd[(size_t)i * 64] = f.step((double)xc[t], b, a);
-        } else {
-            for (int t = 0; t < cnt; ++t, ++i) fwd[(size_t)i * 64] = f.step((double)xc[t], b, a);
+        float xc[CH];
+        {
+            const float4* src = reinterpret_cast<const float4*>(xt[cur] + lane * XS);
+#pragma unroll
+            for (int v = 0; v < CH / 4; ++v) {
+                const float4 t = src[v];
+                xc[4 * v] = t.x; xc[4 * v + 1] = t.y; xc[4 * v + 2] = t.z; xc[4 * v + 3] = t.w;
+            }
         }
-        if (c + 1 < nchunks) store_chunk(xt[cur ^ 1], 0);
+        load_chunk((c + 1) * CH);            // past the frame end the columns clamp; the tail chunk reads what it needs
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { *fwd = f.step((double)xc[t], b, a); fwd += 64; }
+        store_chunk(xt[cur ^ 1], 0);
         __syncthreads();
     }
+    {
+        const float* xc = xt[nfull & 1] + lane * XS;
+#pragma unroll 1
+        for (int t = 0; t < ntail; ++t) { *fwd = f.step((double)xc[t], b, a); fwd += 64; }
+    }
+    __syncthreads();
     // ---- forward pass: right odd extension from x[N-64 .. N-1]
     load_chunk(N - 64); store_chunk(xt[0], 0);
     load_chunk(N - 32); store_chunk(xt[0], CH);
@@ -131,56 +144,61 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
     double ylast = 0.0;
     {
         const float xl = xr[63];
-        for (int k = 0; k < P; ++k, ++i) {
+#pragma unroll 1
+        for (int k = 0; k < P; ++k) {
             const float e = 2.0f * xl - xr[62 - k];
             ylast = f.step((double)e, b, a);
-            fwd[(size_t)i * 64] = ylast;
+            *fwd = ylast;
+            fwd += 64;
         }
     }
-    // all of this lane's forward stores must be visible to its own later loads: same lane, same address,
-    // program order suffices.
+    // fwd now points one row past the last forward sample (row NE); a lane re-reads only what it wrote itself,
+    // so program order is all the ordering the backward pass needs.
 
-    // ---- backward pass over the forward output, newest sample first
+    // ---- backward pass over the forward output, newest sample first.  The last P steps (left extension) only
+    // produce samples that filtfilt crops, so the pass stops at the first frame sample.
     f.init(zi, ylast);
-    double bufA[PF], bufB[PF];
-    auto loadg = [&](double (&buf)[PF], int top) {     // buf[j] = fwd[top - j], j < PF (clamped at 0)
-#pragma unroll
-        for (int j = 0; j < PF; ++j) { const int ii = top - j; buf[j] = fwd[(size_t)(ii < 0 ? 0 : ii) * 64]; }
-    };
+    const double* bwd = fwd - 64;                       // row NE-1; row i is bwd[(i - (NE-1)) * 64]
     double* yrow = yt + lane * YS;
-    auto flush = [&](int n0) {          // write tile columns [n0, n0+32) of 64 rows
+    const int srow = lane >> 4, scol = (lane & 15) * 2;  // flush mapping: 4 rows x 16 double2 per instruction
+    auto flush = [&](int n0) {          // write tile columns [n0, n0+32) of 64 rows as 16-byte stores
         __syncthreads();
 #pragma unroll 4
-        for (int it = 0; it < CH; ++it) {
-            const int r = it * 2 + (lane >> 5), c = lane & 31;
-            const int fr = f0 + r, n = n0 + c;
-            if (fr < p.B && n < N) p.y[((size_t)fr * p.nb + band) * N + n] = yt[r * YS + c];
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + srow;
+            const int fr = f0 + r, n = n0 + scol;
+            if (fr < p.B && n < N) {
+                const double2 v = *reinterpret_cast<const double2*>(yt + r * YS + scol);
+                double* dst = p.y + ((size_t)fr * p.nb + band) * N + n;
+                if (p.y_aligned16 && n + 1 < N) *reinterpret_cast<double2*>(dst) = v;
+                else { dst[0] = v.x; if (n + 1 < N) dst[1] = v.y; }
+            }
         }
         __syncthreads();
     };
-    auto consume = [&](double (&buf)[PF], int top) {
+    // right extension: rows NE-1 .. P+N, no output
+#pragma unroll 1
+    for (int k = 0; k < P; ++k) { (void)f.step(*bwd, b, a); bwd -= 64; }
+    // tail chunk: samples N-1 .. nfull*32
+#pragma unroll 1
+    for (int t = ntail - 1; t >= 0; --t) { yrow[t] = f.step(*bwd, b, a); bwd -= 64; }
+    if (ntail > 0) flush(nfull * CH);
+    // full chunks, 32 rows prefetched into registers one chunk ahead
+    double cur[CH], nxt[CH];
+    auto loadc = [&](double (&buf)[CH], const double* top, bool live) {
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int ii = top - j;
-            if (ii < 0) break;
-            const double y = f.step(buf[j], b, a);
-            const int n = ii - P;
-            if (n >= 0 && n < N) {
-                yrow[n & (CH - 1)] = y;
-                if ((n & (CH - 1)) == 0) flush(n);
-            }
-        }
+        for (int j = 0; j < CH; ++j) buf[j] = live ? top[-(ptrdiff_t)j * 64] : 0.0;
     };
-    int top = NE - 1;
-    loadg(bufA, top);
-    while (top >= 0) {
-        loadg(bufB, top - PF);
-        consume(bufA, top);
-        top -= PF;
-        if (top < 0) break;
-        loadg(bufA, top - PF);
-        consume(bufB, top);
-        top -= PF;
+    if (nfull > 0) loadc(cur, bwd, true);
+#pragma unroll 1
+    for (int c = nfull - 1; c >= 0; --c) {
+        loadc(nxt, bwd - (ptrdiff_t)CH * 64, c > 0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) yrow[CH - 1 - j] = f.step(cur[j], b, a);
+        flush(c * CH);
+        bwd -= (ptrdiff_t)CH * 64;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
     }
 }
 

@@ -13,7 +13,7 @@ namespace echo {
 struct HostTables {
     std::vector<double> taps_rev;   // [nb][kgroups*kR]
     std::vector<double> chirp;      // [nb][mgroups*kR]
-    std::vector<float2> bw, bhat, tw, unpack;
+    std::vector<float2> bw, bhat, tw, post;
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -64,6 +64,7 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     if (N % 2 != 0 || N < 4 || M < 1 || K < 1) return false;
     if (N > kNT * kR || p.L > kNT * kR) return false;
     if (2 * p.n2 - 1 > kFftM) return false;
+    static_assert(kNT >= kFftM / 16, "one thread per butterfly pair");
     p.sig_len = align_up((ceil_div(p.L, kR) + p.mgroups + 1) * kR, 2);
     p.ypad = K - 1 - (K - 1) / 2;
     p.ybuf_len = align_up((ceil_div(N, kR) + p.kgroups + 1) * kR, 2);
@@ -71,27 +72,30 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.off_sig = off; off += align_up(p.sig_len * 8, 16);
     p.off_u = off;
     int u = p.ybuf_len * 8;
-    if (u < kFftM * 8) u = kFftM * 8;
-    if (u < kNT * 28) u = kNT * 28;
+    if (u < kNT * 48) u = kNT * 48;          // reduction scratch (28 B/thread) + median counts (16 B/thread)
     off += align_up(u, 16);
-    p.off_nw = off; off += align_up((nn > 0 ? nn : 1) * 8, 16);
+    p.off_nw = off; off += align_up((nn > 0 ? nn : 1) * 12, 16);   // float64 window + float32 copy
+    p.off_ctap = off; off += align_up((p.kgroups + 1) * kR * 8, 16);
+    p.off_cchirp = off; off += align_up((p.mgroups + 1) * kR * 8, 16);
     p.off_misc = off; off += align_up((int)sizeof(Misc), 16);
     p.smem_bytes = off;
+    p.off_fft = 0; p.spec_smem_bytes = kFftM * 8;
     return off <= 160 * 1024;
 }
 
 inline void build_tables(HostTables& t, const BandParams& p, const double* taps, const double* chirps) {
     const double pi = 3.14159265358979323846;
     const int nb = p.nb, K = p.K, M = p.M, n2 = p.n2, N = p.N;
-    t.taps_rev.assign((size_t)nb * p.kgroups * kR, 0.0);
-    t.chirp.assign((size_t)nb * p.mgroups * kR, 0.0);
+    const int kn = (p.kgroups + 1) * kR, mn = (p.mgroups + 1) * kR;
+    t.taps_rev.assign((size_t)nb * kn, 0.0);
+    t.chirp.assign((size_t)nb * mn, 0.0);
     for (int b = 0; b < nb; ++b) {
-        for (int j = 0; j < K; ++j) t.taps_rev[(size_t)b * p.kgroups * kR + j] = taps[(size_t)b * K + (K - 1 - j)];
-        for (int j = 0; j < M; ++j) t.chirp[(size_t)b * p.mgroups * kR + j] = chirps[(size_t)b * M + j];
+        for (int j = 0; j < K; ++j) t.taps_rev[(size_t)b * kn + j] = taps[(size_t)b * K + (K - 1 - j)];
+        for (int j = 0; j < M; ++j) t.chirp[(size_t)b * mn + j] = chirps[(size_t)b * M + j];
     }
     // Bluestein chirp w[n] = exp(-i*pi*n^2/n2); n^2 reduced mod 2*n2 in integers so the phase stays exact
     std::vector<std::complex<double>> w(n2);
-    t.bw.resize(n2);
+    t.bw.assign((size_t)align_up(n2, 2), mk(0, 0));
     for (int n = 0; n < n2; ++n) {
         const long long r = ((long long)n * n) % (2LL * n2);
         const double ang = -pi * (double)r / (double)n2;
@@ -102,20 +106,34 @@ inline void build_tables(HostTables& t, const BandParams& p, const double* taps,
     bc[0] = std::conj(w[0]);
     for (int n = 1; n < n2; ++n) { bc[n] = std::conj(w[n]); bc[kFftM - n] = std::conj(w[n]); }
     fft_pow2(bc);
+    // chirp-filter spectrum in pass order, scaled by 1/M, stored so that lane u of the middle pass reads
+    // elements (16u + 2jj, 16u + 2jj + 1) at [jj][u][2]
+    const int nu = kFftM / 16;
     t.bhat.resize(kFftM);
     for (int pos = 0; pos < kFftM; ++pos) {
         const std::complex<double> v = bc[pass_order_freq(pos)] / (double)kFftM;
-        t.bhat[pos] = mk(v.real(), v.imag());
+        const int u = pos / 16, j = pos % 16;
+        t.bhat[(size_t)2 * ((j >> 1) * nu + u) + (j & 1)] = mk(v.real(), v.imag());
     }
-    t.tw.resize(kFftM);
-    for (int k = 0; k < kFftM; ++k) {
-        const double ang = -2.0 * pi * (double)k / (double)kFftM;
-        t.tw[k] = mk(std::cos(ang), std::sin(ang));
-    }
-    t.unpack.resize(n2 + 1);
+    // radix-8 pass twiddles: for q in {1024, 128, 16}: W^i, W^2i, W^4i with W = exp(-2*pi*i/(8q)), i < q
+    t.tw.clear();
+    const int qs[3] = {1024, 128, 16};
+    for (int qi = 0; qi < 3; ++qi)
+        for (int m = 1; m <= 4; m *= 2)
+            for (int i = 0; i < qs[qi]; ++i) {
+                const double ang = -2.0 * pi * (double)(i * m) / (double)(8 * qs[qi]);
+                t.tw.push_back(mk(std::cos(ang), std::sin(ang)));
+            }
+    // post table: A[k] = w[ka] (1 - i u_k)/2, B[k] = conj(w[kb]) (1 + i u_k)/2, u_k = exp(-2*pi*i*k/N),
+    // ka = k mod n2, kb = (n2 - k) mod n2
+    t.post.resize((size_t)2 * (n2 + 1));
     for (int k = 0; k <= n2; ++k) {
         const double ang = -2.0 * pi * (double)k / (double)N;
-        t.unpack[k] = mk(std::cos(ang), std::sin(ang));
+        const std::complex<double> u(std::cos(ang), std::sin(ang)), I(0, 1);
+        const int ka = (k == n2) ? 0 : k, kb = (k == 0 || k == n2) ? 0 : n2 - k;
+        const std::complex<double> A = w[ka] * (1.0 - I * u) * 0.5, Bc = std::conj(w[kb]) * (1.0 + I * u) * 0.5;
+        t.post[2 * k] = mk(A.real(), A.imag());
+        t.post[2 * k + 1] = mk(Bc.real(), Bc.imag());
     }
 }
 

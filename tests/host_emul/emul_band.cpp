@@ -19,14 +19,17 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
     HostTables t;
     build_tables(t, p, taps, chirps);
     p.taps_rev = t.taps_rev.data(); p.chirp = t.chirp.data();
-    p.bw = t.bw.data(); p.bhat = t.bhat.data(); p.tw = t.tw.data(); p.unpack = t.unpack.data();
-    p.mode = mode; p.do_corr = do_corr; p.do_spec = spec_out != nullptr; p.spec_db = spec_db;
+    p.bw = t.bw.data(); p.bhat = t.bhat.data(); p.tw = t.tw.data(); p.post = t.post.data();
+    p.mode = mode; p.do_corr = do_corr; p.spec_db = spec_db;
+    std::vector<float> bandf(spec_out ? (size_t)B * nb * N : 0);
+    if (spec_out && (mode == MODE_RX_FIR || mode == MODE_Y_FIR)) { p.bandf_out = bandf.data(); p.specf_in = bandf.data(); }
+    else if (spec_out) p.specd_in = d_in;
     p.rx_in = rx; p.d_in = d_in; p.corr_io = corr_io; p.band_out = band_out; p.spec_out = spec_out;
     p.write_corr_mutated = 1;
     std::vector<BandRes> res((size_t)B * nb);
     p.res_out = res.data();
     const int nt = kNT;
-    std::vector<unsigned char> smem(p.smem_bytes);
+    std::vector<unsigned char> smem(p.smem_bytes > p.spec_smem_bytes ? p.smem_bytes : p.spec_smem_bytes);
     for (int blk = 0; blk < B * nb; ++blk) {
         std::memset(smem.data(), 0xff, smem.size());   // poison: NaN patterns expose reads of unwritten LDS
         unsigned char* s = smem.data();
@@ -34,19 +37,27 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
         PHASE(ph_load(tid, nt, blk, p, s));
         PHASE(ph_fir(tid, nt, blk, p, s));
         PHASE(ph_corr(tid, nt, blk, p, s));
-        PHASE(ph_reduce_a(tid, nt, p, s));
-        PHASE(ph_reduce_b(tid, nt, p, s));
-        PHASE(ph_rank(tid, nt, p, s));
+        PHASE(ph_reduce(tid, nt, p, s));
+        PHASE(ph_rank_count(tid, nt, p, s));
+        PHASE(ph_rank_pick(tid, nt, p, s));
         PHASE(ph_finish(tid, nt, blk, p, s));
-        PHASE(ph_spec_load(tid, nt, p, s));
-        PHASE(ph_fft_r8<false>(tid, nt, 1024, p, s));
-        PHASE(ph_fft_r8<false>(tid, nt, 128, p, s));
-        PHASE(ph_fft_r8<false>(tid, nt, 16, p, s));
-        PHASE(ph_fft_mid(tid, nt, p, s));
-        PHASE(ph_fft_r8<true>(tid, nt, 16, p, s));
-        PHASE(ph_fft_r8<true>(tid, nt, 128, p, s));
-        PHASE(ph_fft_r8<true>(tid, nt, 1024, p, s));
-        PHASE(ph_spec_store(tid, nt, blk, p, s));
+        if (spec_out) {
+            std::memset(smem.data(), 0xff, smem.size());
+            // per-thread register state that the kernel carries across barriers
+            std::vector<Tw3> tw1024(nt), tw128(nt), tw16(nt);
+            std::vector<Bh8> bh(nt);
+            PHASE(tw1024[tid] = fft_tw_load(tid, 1024, p); tw128[tid] = fft_tw_load(tid, 128, p);
+                  tw16[tid] = fft_tw_load(tid, 16, p); bh[tid] = fft_bh_load(tid, p));
+            PHASE(ph_spec_load(tid, nt, blk, p, s));
+            PHASE(ph_fft_r8<false>(tid, 1024, p, s, tw1024[tid]));
+            PHASE(ph_fft_r8<false>(tid, 128, p, s, tw128[tid]));
+            PHASE(ph_fft_r8<false>(tid, 16, p, s, tw16[tid]));
+            PHASE(ph_fft_mid(tid, p, s, bh[tid]));
+            PHASE(ph_fft_r8<true>(tid, 16, p, s, tw16[tid]));
+            PHASE(ph_fft_r8<true>(tid, 128, p, s, tw128[tid]));
+            PHASE(ph_fft_r8<true>(tid, 1024, p, s, tw1024[tid]));
+            PHASE(ph_spec_store(tid, nt, blk, p, s));
+        }
 #undef PHASE
     }
     for (size_t i = 0; i < res.size(); ++i) {
