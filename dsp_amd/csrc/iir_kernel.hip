@@ -202,6 +202,238 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Quad-lane variant: the 2*order states of one (frame, band) are spread over the 4 lanes of a quad (NS = states/4
+// per lane), so a wave owns 16 frames of one band and the sequential instruction stream per sample shrinks from
+// ~42 to ~24 instructions.  The arithmetic per state is unchanged, operation for operation:
+//     y    = z[0] + b[0]*x                         (lane 0 of the quad, broadcast by DPP quad_perm)
+//     z[k] = (z[k+1] + x*b[k+1]) - y*a[k+1]        (z[k+1] of the neighbouring lane arrives by DPP; z[2*order] = 0)
+// Multiplying x by a coefficient that is exactly zero and adding it changes nothing, so no special case is needed.
+// Small batches leave most SIMDs idle in the lane-per-frame kernel; this one trades 2x the total issue slots for
+// 4x the waves, and at large batches both are bound by the forward-scratch traffic to HBM instead.
+__device__ __forceinline__ double dpp_quad_bcast0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_quad_next(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xF9, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NS>
+struct Df2tQuad {
+    double z[NS];
+    double bl[NS], al[NS], b0;
+    bool last;     // sub-lane 3: there is no state beyond its last one
+    // The order of the statements is the intended issue order (the wave issues in order and a float64 result is
+    // ready ~18 cycles after issue): everything that does not need this sample's y goes first, so the only exposed
+    // dependences are y -> broadcast -> y*a -> subtract.  sched_barrier keeps the compiler from sinking the early
+    // work back behind the broadcast.
+    __device__ __forceinline__ double step(double x) {
+        double px[NS], t[NS];
+        const double yb = b0 * x;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) px[j] = x * bl[j];
+        double zn = dpp_quad_next(z[0]);
+        zn = last ? 0.0 : zn;
+        const double yc = z[0] + yb;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) t[j] = ((j + 1 < NS) ? z[j + 1] : zn) + px[j];
+        __builtin_amdgcn_sched_barrier(0);
+        const double y = dpp_quad_bcast0(yc);
+        double py[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) py[j] = y * al[j];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) z[j] = t[j] - py[j];
+        __builtin_amdgcn_sched_barrier(0);
+        return y;
+    }
+};
+
+constexpr int QF = 16;      // frames per wave in the quad kernel
+
+template <int NC>
+__global__ __launch_bounds__(64) void iir_filtfilt_quad_kernel(IirParams p) {
+    constexpr int NS = (NC - 1) / 4;
+    __shared__ __attribute__((aligned(16))) float xt[2][QF * XS];
+    __shared__ __attribute__((aligned(16))) double yt[QF * YS];
+    const int lane = threadIdx.x, u = lane >> 2, sub = lane & 3;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * p.nb), rem = id % (8 * p.nb);
+    const int band = rem / 8, tile = grp * 8 + rem % 8;
+    if (tile >= p.ntiles) return;
+    const int N = p.N, P = p.P, NE = N + 2 * P;
+    const int f0 = tile * QF;
+
+    Df2tQuad<NS> f;
+    f.b0 = p.b[band * NC];
+    f.last = sub == 3;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        f.bl[j] = p.b[band * NC + NS * sub + j + 1];
+        f.al[j] = p.a[band * NC + NS * sub + j + 1];
+    }
+    const double* zi = p.zi + band * (NC - 1) + NS * sub;
+    auto init = [&](double x0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) f.z[j] = zi[j] * x0;
+    };
+
+    // cooperative load of columns [c0, c0+32) of the 16 rows: lane -> (row it*2 + lane/32, column lane%32)
+    const int lrow = lane >> 5, lcol = lane & 31;
+    constexpr int LI = QF / 2;
+    float pre[LI];
+    auto load_chunk = [&](int c0) {
+        int c = c0 + lcol;
+        c = c < 0 ? 0 : (c > N - 1 ? N - 1 : c);
+#pragma unroll
+        for (int it = 0; it < LI; ++it) {
+            int fr = f0 + it * 2 + lrow;
+            fr = fr < p.B ? fr : p.B - 1;
+            pre[it] = p.rx[(size_t)fr * N + c];
+        }
+    };
+    auto store_chunk = [&](float* dst, int colofs) {
+#pragma unroll
+        for (int it = 0; it < LI; ++it) dst[(it * 2 + lrow) * XS + colofs + lcol] = pre[it];
+    };
+
+    double* fwd = p.fwd + ((size_t)(band * p.ntiles + tile) * NE) * QF + u;   // row i at fwd[i * QF]
+    // every lane of a quad holds the same y after the broadcast and stores it to the same address: no divergence
+
+    // ---- forward pass: left odd extension from x[0..P]
+    load_chunk(0);  store_chunk(xt[0], 0);
+    load_chunk(CH); store_chunk(xt[0], CH);
+    __syncthreads();
+    const float* xr = xt[0] + u * XS;
+    {
+        const float x0 = xr[0];
+        init((double)(2.0f * x0 - xr[P]));
+#pragma unroll 1
+        for (int k = 0; k < P; ++k) {
+            const float e = 2.0f * x0 - xr[P - k];
+            const double y = f.step((double)e);
+            *fwd = y;
+            fwd += QF;
+        }
+    }
+    __syncthreads();
+    // ---- forward pass: the frame, 32-sample chunks in registers, next chunk prefetched
+    const int nfull = N / CH, ntail = N - nfull * CH;
+    load_chunk(0); store_chunk(xt[0], 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < nfull; ++c) {
+        const int cur = c & 1;
+        float xc[CH];
+        {
+            const float4* src = reinterpret_cast<const float4*>(xt[cur] + u * XS);
+#pragma unroll
+            for (int v = 0; v < CH / 4; ++v) {
+                const float4 t = src[v];
+                xc[4 * v] = t.x; xc[4 * v + 1] = t.y; xc[4 * v + 2] = t.z; xc[4 * v + 3] = t.w;
+            }
+        }
+        load_chunk((c + 1) * CH);
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            const double y = f.step((double)xc[t]);
+            fwd[t * QF] = y;
+        }
+        fwd += CH * QF;
+        store_chunk(xt[cur ^ 1], 0);
+        __syncthreads();
+    }
+    {
+        const float* xc = xt[nfull & 1] + u * XS;
+#pragma unroll 1
+        for (int t = 0; t < ntail; ++t) {
+            const double y = f.step((double)xc[t]);
+            *fwd = y;
+            fwd += QF;
+        }
+    }
+    __syncthreads();
+    // ---- forward pass: right odd extension from x[N-64 .. N-1]
+    load_chunk(N - 64); store_chunk(xt[0], 0);
+    load_chunk(N - 32); store_chunk(xt[0], CH);
+    __syncthreads();
+    double ylast = 0.0;
+    {
+        const float xl = xr[63];
+#pragma unroll 1
+        for (int k = 0; k < P; ++k) {
+            const float e = 2.0f * xl - xr[62 - k];
+            ylast = f.step((double)e);
+            *fwd = ylast;
+            fwd += QF;
+        }
+    }
+    // The four lanes of a quad re-read what lane 0 of the same quad stored: same wave, program order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- backward pass, newest sample first; stops at the first frame sample (the rest is cropped)
+    init(ylast);
+    const double* bwd = fwd - QF;
+    double* yrow = yt + u * YS;
+    const int srow = lane >> 4, scol = (lane & 15) * 2;
+    auto flush = [&](int n0) {          // tile columns [n0, n0+32) of 16 rows as 16-byte stores
+        __syncthreads();
+        double2 v[QF / 4];
+#pragma unroll
+        for (int it = 0; it < QF / 4; ++it) v[it] = *reinterpret_cast<const double2*>(yt + (it * 4 + srow) * YS + scol);
+#pragma unroll
+        for (int it = 0; it < QF / 4; ++it) {
+            const int fr = f0 + it * 4 + srow, n = n0 + scol;
+            if (fr < p.B && n < N) {
+                double* dst = p.y + ((size_t)fr * p.nb + band) * N + n;
+                if (p.y_aligned16 && n + 1 < N) *reinterpret_cast<double2*>(dst) = v[it];
+                else { dst[0] = v[it].x; if (n + 1 < N) dst[1] = v[it].y; }
+            }
+        }
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = 0; k < P; ++k) { (void)f.step(*bwd); bwd -= QF; }
+#pragma unroll 1
+    for (int t = ntail - 1; t >= 0; --t) { const double y = f.step(*bwd); yrow[t] = y; bwd -= QF; }
+    if (ntail > 0) flush(nfull * CH);
+    double cur[CH], nxt[CH];
+    auto loadc = [&](double (&buf)[CH], const double* top, bool live) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) buf[j] = live ? top[-(ptrdiff_t)j * QF] : 0.0;
+    };
+    if (nfull > 0) loadc(cur, bwd, true);
+#pragma unroll 1
+    for (int c = nfull - 1; c >= 0; --c) {
+        loadc(nxt, bwd - (ptrdiff_t)CH * QF, c > 0);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const double y = f.step(cur[j]); yrow[CH - 1 - j] = y; }
+        flush(c * CH);
+        bwd -= (ptrdiff_t)CH * QF;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+    }
+}
+
+template __global__ void iir_filtfilt_quad_kernel<13>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<17>(IirParams);
+
+int launch_iir_quad(const IirParams& p, int ncoef, hipStream_t s) {
+    const int groups = (p.ntiles + 7) / 8;
+    dim3 grid(groups * 8 * p.nb), block(64);
+    if (ncoef == 13)      hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13>), grid, block, 0, s, p);
+    else if (ncoef == 17) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17>), grid, block, 0, s, p);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 #define IIR_INST(NC, BZ) template __global__ void iir_filtfilt_kernel<NC, BZ>(IirParams);
 IIR_INST(13, true) IIR_INST(13, false) IIR_INST(17, true) IIR_INST(17, false)
 
