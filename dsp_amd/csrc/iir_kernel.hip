@@ -404,21 +404,29 @@ __global__ __launch_bounds__(64) void iir_filtfilt_quad_kernel(IirParams p) {
 #pragma unroll 1
     for (int t = ntail - 1; t >= 0; --t) { const double y = f.step(*bwd); yrow[t] = y; bwd -= QF; }
     if (ntail > 0) flush(nfull * CH);
-    double cur[CH], nxt[CH];
-    auto loadc = [&](double (&buf)[CH], const double* top, bool live) {
+    // Full chunks.  The forward output comes back from HBM (the scratch is far larger than the caches), so each
+    // chunk's 32 rows are requested two chunks (about 3 us of arithmetic) before they are consumed: three register
+    // buffers rotate through a loop unrolled by three.
+    double bufA[CH], bufB[CH], bufC[CH];
+    const double* row0 = bwd - (ptrdiff_t)(nfull * CH - 1) * QF;       // row of frame sample 0
+    auto loadc = [&](double (&buf)[CH], int c) {                        // rows of chunk c, newest first; c < 0 clamps
+        const double* top = row0 + (ptrdiff_t)((c < 0 ? 0 : c) * CH + CH - 1) * QF;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) buf[j] = live ? top[-(ptrdiff_t)j * QF] : 0.0;
+        for (int j = 0; j < CH; ++j) buf[j] = top[-(ptrdiff_t)j * QF];
     };
-    if (nfull > 0) loadc(cur, bwd, true);
-#pragma unroll 1
-    for (int c = nfull - 1; c >= 0; --c) {
-        loadc(nxt, bwd - (ptrdiff_t)CH * QF, c > 0);
+    auto run = [&](const double (&buf)[CH], int c) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { const double y = f.step(cur[j]); yrow[CH - 1 - j] = y; }
+        for (int j = 0; j < CH; ++j) yrow[CH - 1 - j] = f.step(buf[j]);
         flush(c * CH);
-        bwd -= (ptrdiff_t)CH * QF;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+    };
+    if (nfull > 0) { loadc(bufA, nfull - 1); loadc(bufB, nfull - 2); }
+#pragma unroll 1
+    for (int c = nfull - 1; c >= 0; c -= 3) {
+        loadc(bufC, c - 2); run(bufA, c);
+        if (c - 1 < 0) break;
+        loadc(bufA, c - 3); run(bufB, c - 1);
+        if (c - 2 < 0) break;
+        loadc(bufB, c - 4); run(bufC, c - 2);
     }
 }
 

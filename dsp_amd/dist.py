@@ -1,0 +1,91 @@
+"""Multi-GPU driver: one process per GPU, frames (or whole streams) sharded across ranks, per-frame result
+records gathered with one collective (RCCL on GPUs, gloo on CPU tensors in the unit tests).
+
+The reference has no distributed path; the only exchange this hot path needs is the gather of the 64-byte
+result rows (range, confidence, SNR per band, fused range, Kalman output) -- spectra stay on the rank that
+produced them.  Sharding rules:
+  * independent frames: contiguous blocks, rank r takes frames [r*B/W, (r+1)*B/W) (remainder to the low ranks);
+  * Kalman streams: a stream is sequential in time, so streams -- never time steps -- are split across ranks.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) per rank; the first total % world ranks get one extra item."""
+    base, rem = divmod(total, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    return shard_bounds(total, world)[rank]
+
+
+def local_stream_frames(rx_time_major: torch.Tensor, n_streams: int, rank: int, world: int):
+    """rx [T*S, N] time-major over S streams -> this rank's [T*S_r, N] (still time-major) and its stream range."""
+    ts, n = rx_time_major.shape
+    t = ts // n_streams
+    s0, s1 = shard_range(n_streams, rank, world)
+    local = rx_time_major.reshape(t, n_streams, n)[:, s0:s1].reshape(t * (s1 - s0), n)
+    return local.contiguous(), (s0, s1)
+
+
+def gather_records(rec_local: torch.Tensor, counts: Optional[List[int]] = None, group=None) -> torch.Tensor:
+    """All-gather of per-frame record rows [B_r, 64] uint8 -> [sum B_r, 64] in rank order, on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return rec_local
+    world = dist.get_world_size(group)
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty((world * rec_local.shape[0],) + tuple(rec_local.shape[1:]), dtype=rec_local.dtype,
+                          device=rec_local.device)
+        dist.all_gather_into_tensor(out, rec_local.contiguous(), group=group)
+        return out
+    # uneven shards: pad every contribution to the largest count, gather once, drop the padding
+    cmax = max(counts)
+    padded = torch.zeros((cmax,) + tuple(rec_local.shape[1:]), dtype=rec_local.dtype, device=rec_local.device)
+    padded[: rec_local.shape[0]] = rec_local
+    out = torch.empty((world * cmax,) + tuple(rec_local.shape[1:]), dtype=rec_local.dtype, device=rec_local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * cmax: r * cmax + c] for r, c in enumerate(counts)], dim=0)
+
+
+def gather_stream_records(rec_local: torch.Tensor, n_streams: int, group=None) -> torch.Tensor:
+    """Records of stream-sharded, time-major batches -> global time-major order [T*S, 64]."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return rec_local
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(n_streams, world)
+    s_r = [hi - lo for lo, hi in bounds]
+    t = rec_local.shape[0] // s_r[dist.get_rank(group)]
+    flat = gather_records(rec_local, [t * s for s in s_r], group)
+    parts, off = [], 0
+    for s in s_r:
+        parts.append(flat[off:off + t * s].reshape(t, s, -1))
+        off += t * s
+    return torch.cat(parts, dim=1).reshape(t * n_streams, -1)
+
+
+def process_sharded(engine, rx_global: torch.Tensor, n_streams: Optional[int] = None, kalman=None,
+                    want_spectra: bool = False, group=None):
+    """Run the chain on this rank's shard of rx_global and gather the records of all ranks.
+    With n_streams the batch is time-major over streams and is split by stream; otherwise by frame.
+    Returns (records of all frames in global order, this rank's spectra or None)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if n_streams:
+        local, (s0, s1) = local_stream_frames(rx_global, n_streams, rank, world)
+        rec, spec = engine.chain(local, n_streams=s1 - s0, kalman=kalman, want_spectra=want_spectra)
+        return gather_stream_records(rec, n_streams, group), spec
+    lo, hi = shard_range(rx_global.shape[0], rank, world)
+    rec, spec = engine.chain(rx_global[lo:hi], want_spectra=want_spectra)
+    counts = [b - a for a, b in shard_bounds(rx_global.shape[0], world)]
+    return gather_records(rec, counts, group), spec
