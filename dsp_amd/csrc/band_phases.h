@@ -67,6 +67,8 @@ struct BandParams {
     const float2* tw;                // radix-8 pass twiddles: for q in {1024,128,16}: [3][q] = W^i, W^2i, W^4i, W = exp(-2*pi*i/(8q))
     const float2* post;              // [n2+1][2]  A[k] = w[k](1 - i u_k)/2, B[k] = conj(w[n2-k])(1 + i u_k)/2, u_k = exp(-2*pi*i*k/N)
     int off_ctap, off_cchirp;        // LDS copies of this band's coefficient tables
+    int off_cchirp32;                // float32 copy of the chirp (its values are float32 by construction)
+    int corr_fast;                   // chain only: float32 correlation where only max|corr| is needed (see ph_corr)
     // LDS carve (byte offsets, 16-B aligned)
     int off_sig, sig_len;            // double[sig_len]: band_sig at [M-1, M-1+N), zeros elsewhere
     int off_u;                       // union: double ybuf[ybuf_len] | reduction scratch + median counts
@@ -130,6 +132,33 @@ ECHO_HD void sliding_dot(const double* in, const double* c, int ngroups, double 
     if (g < ngroups) dot_block(w, c0, in + (g + 1) * kR, acc);
 }
 
+// float32 variant: the window comes from the float64 LDS signal (converted on load), coefficients from a float copy.
+ECHO_HD void dot_block_f(float (&w)[kR], const float (&c)[kR], const double* nx, float (&acc)[kR]) {
+    lds_cptr_t vx = ECHO_LDS_CPTR(nx);
+#pragma unroll
+    for (int t = 0; t < kR; ++t) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) acc[r] = fmaf(w[(r + t) % kR], c[t], acc[r]);
+        w[t] = (float)vx[t];
+    }
+}
+
+ECHO_HD void sliding_dot_f(const double* in, const float* c, int ngroups, float (&acc)[kR]) {
+    float w[kR], c0[kR], c1[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { w[r] = (float)in[r]; c0[r] = c[r]; acc[r] = 0.f; }
+    int g = 0;
+    for (; g + 1 < ngroups; g += 2) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c1[r] = c[(g + 1) * kR + r];
+        dot_block_f(w, c0, in + (g + 1) * kR, acc);
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c0[r] = c[(g + 2) * kR + r];
+        dot_block_f(w, c1, in + (g + 2) * kR, acc);
+    }
+    if (g < ngroups) dot_block_f(w, c0, in + (g + 1) * kR, acc);
+}
+
 // ---------------------------------------------------------------- phase 0: stage the input in LDS
 ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
     double* sig = lds_d(smem, p.off_sig);
@@ -144,7 +173,8 @@ ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned cha
     if (p.do_corr && p.mode != MODE_CORR) {
         double* cc = lds_d(smem, p.off_cchirp);
         const int n = (p.mgroups + 1) * kR;
-        for (int i = tid; i < n; i += nt) cc[i] = p.chirp[(size_t)band * n + i];
+        float* cf = reinterpret_cast<float*>(smem + p.off_cchirp32);
+        for (int i = tid; i < n; i += nt) { const double v = p.chirp[(size_t)band * n + i]; cc[i] = v; cf[i] = (float)v; }
     }
     if (p.mode == MODE_RX_FIR || p.mode == MODE_Y_FIR) {
         // all global loads of a batch are issued before the first LDS store, so their latencies overlap
@@ -218,9 +248,46 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
     double* nw = lds_d(smem, p.off_nw);
     float* nwf = reinterpret_cast<float*>(nw + p.noise_n);
     double* red = lds_d(smem, p.off_u);            // [slots] best | [slots] amp | [slots] sumsq | int[slots] idx
-    const int k0 = tid * kR;
     double best = -INFINITY, amp = 0.0, sumsq = 0.0;
     int bidx = 0x7fffffff;
+    // Fast split (chain, median detector): only pos[min_delay:] = corr[half+min_delay:] feeds the argmax, the noise
+    // floor and the SNR, so only those outputs are evaluated in float64.  corr[:half] contributes nothing but
+    // max|corr| (amplitude enters the confidence through min(amp/0.1, 1) and is compared at 1e-4), so the first
+    // half of the workgroup evaluates it in float32 at twice the rate; the blind zone is zero by definition and is
+    // not evaluated at all.
+    const bool fast = p.corr_fast && p.mode != MODE_CORR && !p.corr_io && p.detector == 0;
+    const int kstart = p.half + p.min_delay;
+    const int nlow = nt / 2;                               // threads [0, nlow): float32 part, [nlow, nt): float64 part
+    if (fast && (p.half + kR - 1) / kR <= nlow && (p.L - kstart + kR - 1) / kR <= nt - nlow) {
+        if (tid < nlow) {
+            const int k0 = tid * kR;
+            if (k0 < p.half) {
+                float acc[kR];
+                sliding_dot_f(sig + k0, reinterpret_cast<const float*>(smem + p.off_cchirp32), p.mgroups, acc);
+#pragma unroll
+                for (int r = 0; r < kR; ++r)
+                    if (k0 + r < p.half) { const double av = fabs((double)acc[r]); amp = av > amp ? av : amp; }
+            }
+        } else {
+            const int k0 = kstart + (tid - nlow) * kR;
+            if (k0 < p.L) {
+                double acc[kR];
+                sliding_dot(sig + k0, lds_d(smem, p.off_cchirp), p.mgroups, acc);
+#pragma unroll
+                for (int r = 0; r < kR; ++r) {
+                    const int k = k0 + r;
+                    if (k >= p.L) continue;
+                    const double v = acc[r], av = fabs(v);
+                    const int q = k - p.half, w = q - p.min_delay;
+                    amp = av > amp ? av : amp;
+                    if (v > best) { best = v; bidx = q; }
+                    if (w < p.noise_n) { nw[w] = av; nwf[w] = (float)av; }
+                }
+            }
+        }
+        if (p.min_delay > 0 && tid == 0 && 0.0 > best) { best = 0.0; bidx = 0; }   // the zeroed blind zone: pos[0] = 0
+    } else {
+    const int k0 = tid * kR;
     if (k0 < p.L) {
         double acc[kR];
         if (p.mode == MODE_CORR) {
@@ -256,6 +323,7 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
                 }
             }
         }
+    }
     }
     // one partial per wavefront on the device (butterfly over the 64 lanes), one per thread on the host
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -338,7 +338,7 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         if (rc) return rc;
         if (prof) (void)hipEventRecord(ev[1], s);
         BandParams p = h->base;
-        p.mode = MODE_Y_FIR; p.do_corr = 1;
+        p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
         p.d_in = h->d_y; p.res_out = h->d_res;
         p.bandf_out = spec_db ? h->d_bandf : nullptr;
         rc = launch_band(p, n, s);

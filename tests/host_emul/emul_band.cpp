@@ -12,7 +12,7 @@ using namespace echo;
 extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n, int detector, double gate,
                          const double* taps, const double* chirps, int mode, const float* rx, const double* d_in,
                          double* corr_io, int B, double* band_out, float* spec_out, int spec_db, int do_corr,
-                         double* snr, double* amp, int* peak) {
+                         double* snr, double* amp, int* peak, int corr_fast) {
     BandParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_band(p, N, M, K, nb, min_delay, noise_n, detector, gate)) return -2;
@@ -26,6 +26,8 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
     else if (spec_out) p.specd_in = d_in;
     p.rx_in = rx; p.d_in = d_in; p.corr_io = corr_io; p.band_out = band_out; p.spec_out = spec_out;
     p.write_corr_mutated = 1;
+    p.corr_fast = corr_fast;
+    if (corr_fast) p.corr_io = nullptr;
     std::vector<BandRes> res((size_t)B * nb);
     p.res_out = res.data();
     const int nt = kNT;

@@ -22,7 +22,7 @@ def emul():
     subprocess.check_call(["make", "-C", EMUL], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(os.path.join(EMUL, "libemul.so"))
     P, I = ctypes.c_void_p, ctypes.c_int
-    lib.emul_band.argtypes = [I] * 7 + [ctypes.c_double, P, P, I, P, P, P, I, P, P, I, I, P, P, P]
+    lib.emul_band.argtypes = [I] * 7 + [ctypes.c_double, P, P, I, P, P, P, I, P, P, I, I, P, P, P, I]
     return lib
 
 
@@ -30,7 +30,7 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-def _run(lib, cfg, t, mode, rx=None, d_in=None, corr_io=None, want_spec=True, do_corr=1):
+def _run(lib, cfg, t, mode, rx=None, d_in=None, corr_io=None, want_spec=True, do_corr=1, corr_fast=0):
     B = len(rx) if rx is not None else len(d_in)
     nb, N = cfg.n_bands, cfg.n_rx
     band = np.zeros((B, nb, N)); spec = np.zeros((B, nb, cfg.n_bins), np.float32) if want_spec else None
@@ -39,7 +39,7 @@ def _run(lib, cfg, t, mode, rx=None, d_in=None, corr_io=None, want_spec=True, do
     taps = np.ascontiguousarray(t.taps); chirps = np.ascontiguousarray(t.chirps)
     rc = lib.emul_band(N, cfg.n_chirp, cfg.FIR_TAPS, nb, cfg.min_delay, cfg.noise_n, cfg.DETECTOR, cfg.SNR_GATE_DB,
                        _ptr(taps), _ptr(chirps), mode, _ptr(rx), _ptr(d_in), _ptr(corr), B, _ptr(band), _ptr(spec), 1,
-                       do_corr, _ptr(snr), _ptr(amp), _ptr(peak))
+                       do_corr, _ptr(snr), _ptr(amp), _ptr(peak), corr_fast)
     assert rc == 0
     return dict(band=band, corr=corr, spec=spec, snr=snr, amp=amp, peak=peak)
 
@@ -62,6 +62,10 @@ def test_emulated_band_and_spectrum_kernels(which, emul, gold_default, gold_dist
     lin, ref = 10 ** (r["spec"].astype(np.float64) / 20), 10 ** (g["stage_spec_db"].astype(np.float64) / 20)
     live = ref.max(axis=-1) > 1e-9
     assert ((np.abs(lin - ref).max(axis=-1) / np.maximum(ref.max(axis=-1), 1e-300))[live] <= 1e-5).all()
+    # the chain's split-precision correlation: float64 where the detector looks, float32 where only max|corr| is taken
+    f = _run(emul, cfg, t, mode=1, d_in=np.ascontiguousarray(y), want_spec=False, corr_fast=1)
+    assert np.array_equal(f["peak"], r["peak"]) and np.array_equal(f["snr"], r["snr"])       # detector inputs unchanged
+    np.testing.assert_allclose(f["amp"], r["amp"], rtol=2e-6)
 
 
 def test_emulated_first_strong_peak_mutates_like_reference(emul, gold_default):
