@@ -63,7 +63,7 @@ def load():
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_set_profiling.argtypes = [P, I]
-    lib.echo_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.echo_last_kernel_ms.argtypes = [P] + [C.POINTER(C.c_float)] * 4
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:

@@ -67,6 +67,7 @@ struct BandParams {
     const float2* tw;                // radix-8 pass twiddles: for q in {1024,128,16}: [3][q] = W^i, W^2i, W^4i, W = exp(-2*pi*i/(8q))
     const float2* post;              // [n2+1][2]  A[k] = w[k](1 - i u_k)/2, B[k] = conj(w[n2-k])(1 + i u_k)/2, u_k = exp(-2*pi*i*k/N)
     int off_ctap, off_cchirp;        // LDS copies of this band's coefficient tables
+    int off_ctap32;                  // float32 copy of the reversed taps
     int off_cchirp32;                // float32 copy of the chirp (its values are float32 by construction)
     int corr_fast;                   // chain only: float32 correlation where only max|corr| is needed (see ph_corr)
     // LDS carve (byte offsets, 16-B aligned)
@@ -168,7 +169,8 @@ ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned cha
     if (p.mode == MODE_RX_FIR || p.mode == MODE_Y_FIR) {
         double* ct = lds_d(smem, p.off_ctap);
         const int n = (p.kgroups + 1) * kR;
-        for (int i = tid; i < n; i += nt) ct[i] = p.taps_rev[(size_t)band * n + i];
+        float* cf = reinterpret_cast<float*>(smem + p.off_ctap32);
+        for (int i = tid; i < n; i += nt) { const double v = p.taps_rev[(size_t)band * n + i]; ct[i] = v; cf[i] = (float)v; }
     }
     if (p.do_corr && p.mode != MODE_CORR) {
         double* cc = lds_d(smem, p.off_cchirp);
@@ -221,8 +223,19 @@ ECHO_HD void ph_fir(int tid, int nt, int blk, const BandParams& p, unsigned char
     double* sig = lds_d(smem, p.off_sig);
     const int n0 = tid * kR;
     if (n0 >= p.N) return;
+    // Chain fast path: band_sig[n] below nexact only reaches the float32 half of the correlation and the float32
+    // spectrum, so those lanes run the FIR in float32 too (float64 is kept wherever the detector can see it).
+    const int nexact = p.half + p.min_delay - (p.M - 1);
+    const bool fast = p.corr_fast && p.mode == MODE_Y_FIR && !p.band_out && !p.corr_io && p.detector == 0;
     double acc[kR];
-    sliding_dot(yb + n0, lds_d(smem, p.off_ctap), p.kgroups, acc);
+    if (fast && n0 + kR <= nexact) {
+        float accf[kR];
+        sliding_dot_f(yb + n0, reinterpret_cast<const float*>(smem + p.off_ctap32), p.kgroups, accf);
+#pragma unroll
+        for (int r = 0; r < kR; ++r) acc[r] = (double)accf[r];
+    } else {
+        sliding_dot(yb + n0, lds_d(smem, p.off_ctap), p.kgroups, acc);
+    }
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
         const int n = n0 + r;

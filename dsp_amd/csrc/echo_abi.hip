@@ -33,7 +33,7 @@ struct EchoHandle {
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
-    std::vector<hipEvent_t> ev;            // 4 events per slot
+    std::vector<hipEvent_t> ev;            // 5 events per slot: start, after IIR, after band, after spectrum, end
     int prof_slots = 0, prof_used = 0;
 };
 
@@ -186,7 +186,7 @@ int echo_set_profiling(EchoHandle* h, int slots) {
     if (!h || slots < 0) return ECHO_ERR_INVALID;
     h->prof = slots > 0;
     h->prof_used = 0;
-    while ((int)h->ev.size() < 4 * slots) {
+    while ((int)h->ev.size() < 5 * slots) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
         h->ev.push_back(e);
@@ -195,21 +195,23 @@ int echo_set_profiling(EchoHandle* h, int slots) {
     return ECHO_OK;
 }
 
-int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms) {
+int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spec_ms, float* fuse_ms) {
     if (!h || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
-    double a = 0, b = 0, c = 0;
+    double acc[4] = {0, 0, 0, 0};
     for (int k = 0; k < h->prof_used; ++k) {
-        hipEvent_t* e = &h->ev[4 * k];
-        if (hipEventSynchronize(e[3]) != hipSuccess) return ECHO_ERR_HIP;
-        float x = 0, y = 0, z = 0;
-        if (hipEventElapsedTime(&x, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&y, e[1], e[2]) != hipSuccess ||
-            hipEventElapsedTime(&z, e[2], e[3]) != hipSuccess) return ECHO_ERR_HIP;
-        a += x; b += y; c += z;
+        hipEvent_t* e = &h->ev[5 * k];
+        if (hipEventSynchronize(e[4]) != hipSuccess) return ECHO_ERR_HIP;
+        for (int j = 0; j < 4; ++j) {
+            float x = 0;
+            if (hipEventElapsedTime(&x, e[j], e[j + 1]) != hipSuccess) return ECHO_ERR_HIP;
+            acc[j] += x;
+        }
     }
     const double n = (double)h->prof_used;
-    if (iir_ms) *iir_ms = (float)(a / n);
-    if (band_ms) *band_ms = (float)(b / n);
-    if (fuse_ms) *fuse_ms = (float)(c / n);
+    if (iir_ms) *iir_ms = (float)(acc[0] / n);
+    if (band_ms) *band_ms = (float)(acc[1] / n);
+    if (spec_ms) *spec_ms = (float)(acc[2] / n);
+    if (fuse_ms) *fuse_ms = (float)(acc[3] / n);
     h->prof_used = 0;
     return ECHO_OK;
 }
@@ -332,7 +334,7 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
         const bool prof = h->prof && f0 == 0 && h->prof_used < h->prof_slots;
-        hipEvent_t* ev = prof ? &h->ev[4 * h->prof_used] : nullptr;
+        hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
         rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
         if (rc) return rc;
@@ -343,13 +345,14 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         p.bandf_out = spec_db ? h->d_bandf : nullptr;
         rc = launch_band(p, n, s);
         if (rc) return rc;
+        if (prof) (void)hipEventRecord(ev[2], s);
         if (spec_db) {
             BandParams q = h->base;
             q.spec_db = 1; q.specf_in = h->d_bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
             rc = launch_spec(q, n, s);
             if (rc) return rc;
         }
-        if (prof) (void)hipEventRecord(ev[2], s);
+        if (prof) (void)hipEventRecord(ev[3], s);
         rc = launch_fuse(fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n), s);
         if (rc) return rc;
         if (kal) {
@@ -360,7 +363,7 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
             rc = launch_kalman(k, s);
             if (rc) return rc;
         }
-        if (prof) { (void)hipEventRecord(ev[3], s); ++h->prof_used; }
+        if (prof) { (void)hipEventRecord(ev[4], s); ++h->prof_used; }
     }
     return ECHO_OK;
 }

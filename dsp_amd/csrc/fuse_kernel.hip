@@ -66,28 +66,40 @@ __global__ void fuse_kernel(FuseParams p) {
     if (p.valid_any) p.valid_any[i] = nvalid > 0 ? 1 : 0;
 }
 
-// One lane per stream, sequential over the stream's T frames (time-major layout: index t*S + s).
+// One lane per stream, sequential over the stream's T frames (time-major layout: index t*S + s).  Inputs are
+// fetched eight steps ahead so the loop is not a chain of dependent global loads.
 __global__ void kalman_kernel(KalmanParams p) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= p.S) return;
     double x = p.x[s], pp = p.p[s];
     bool init = p.init[s] != 0;
     EchoResult* rec = reinterpret_cast<EchoResult*>(p.rec);
-    for (int t = 0; t < p.T; ++t) {
-        const size_t i = (size_t)t * p.S + s;
-        if (p.valid[i]) {
-            const double z = p.z[i];
-            if (!init) { x = z; init = true; }
-            else {
-                pp += p.q;
-                const double k = pp / (pp + p.r);
-                x += k * (z - x);
-                pp *= (1 - k);
-            }
+    constexpr int U = 8;
+    for (int t0 = 0; t0 < p.T; t0 += U) {
+        double z[U]; uint8_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u < p.T ? t0 + u : p.T - 1;
+            const size_t i = (size_t)t * p.S + s;
+            z[u] = p.z[i]; v[u] = p.valid[i];
         }
-        const double o = init ? x : 0.0;
-        if (p.out) p.out[i] = o;
-        if (rec) rec[i].kalman = (float)o;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t0 + u >= p.T) break;
+            const size_t i = (size_t)(t0 + u) * p.S + s;
+            if (v[u]) {
+                if (!init) { x = z[u]; init = true; }
+                else {
+                    pp += p.q;
+                    const double k = pp / (pp + p.r);
+                    x += k * (z[u] - x);
+                    pp *= (1 - k);
+                }
+            }
+            const double o = init ? x : 0.0;
+            if (p.out) p.out[i] = o;
+            if (rec) rec[i].kalman = (float)o;
+        }
     }
     p.x[s] = x; p.p[s] = pp; p.init[s] = init ? 1 : 0;
 }

@@ -77,6 +77,7 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.off_nw = off; off += align_up((nn > 0 ? nn : 1) * 12, 16);   // float64 window + float32 copy
     p.off_ctap = off; off += align_up((p.kgroups + 1) * kR * 8, 16);
     p.off_cchirp = off; off += align_up((p.mgroups + 1) * kR * 8, 16);
+    p.off_ctap32 = off; off += align_up((p.kgroups + 1) * kR * 4, 16);
     p.off_cchirp32 = off; off += align_up((p.mgroups + 1) * kR * 4, 16);
     p.off_misc = off; off += align_up((int)sizeof(Misc), 16);
     p.smem_bytes = off;

@@ -175,9 +175,10 @@ class EchoEngine:
         _lib.check(self.lib.echo_set_profiling(self._h, int(slots)), "echo_set_profiling")
 
     def last_kernel_ms(self):
-        a, b, c = C.c_float(), C.c_float(), C.c_float()
-        _lib.check(self.lib.echo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)), "echo_last_kernel_ms")
-        return {"iir": a.value, "band": b.value, "fuse": c.value}
+        a, b, c, d = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        _lib.check(self.lib.echo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)),
+                   "echo_last_kernel_ms")
+        return {"iir": a.value, "band": b.value, "spec": c.value, "fuse": d.value}
 
 
 def records_to_numpy(rec: torch.Tensor) -> np.ndarray:

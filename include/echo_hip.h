@@ -147,10 +147,10 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
 
 /* Kernel timing with HIP events recorded on the call's own stream: echo_set_profiling(h, slots) arms the next
  * `slots` echo_chain calls (0 disarms); echo_last_kernel_ms waits for them and returns the average device time
- * in milliseconds of the IIR kernel, the band kernel and the fusion(+Kalman) kernels over the armed calls
+ * in milliseconds of the IIR kernel, the band kernel, the spectrum kernel and the fusion(+Kalman) kernels over the armed calls
  * (first internal pass of each call), then re-arms from slot 0.  No counterpart in the reference. */
 int echo_set_profiling(EchoHandle* h, int slots);
-int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* fuse_ms);
+int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spec_ms, float* fuse_ms);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
     p.rx_in = rx; p.d_in = d_in; p.corr_io = corr_io; p.band_out = band_out; p.spec_out = spec_out;
     p.write_corr_mutated = 1;
     p.corr_fast = corr_fast;
-    if (corr_fast) p.corr_io = nullptr;
+    if (corr_fast) { p.corr_io = nullptr; p.band_out = nullptr; }
     std::vector<BandRes> res((size_t)B * nb);
     p.res_out = res.data();
     const int nt = kNT;
