@@ -33,30 +33,72 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (one-core leg)")
+    ap.add_argument("--cpu-workers", type=int, default=16, help="processes of the all-cores CPU-baseline leg")
+    ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
+                    help="internal: run the CPU oracle on one frame shard and print the seconds taken")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, tables, rx_host, budget_s):
-    """The oracle (NumPy/SciPy restatement of the reference chain) on one host core, bounded sample."""
+def _cpu_worker(job):
+    """One host process of the all-cores baseline: rebuilds the tables and runs the oracle on its own frame shard."""
+    start, count, n_streams = job
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    from dsp_amd.config import optimized_config
+    from dsp_amd.design import build_tables
+    from dsp_amd.synth import synth_frames
+    from oracle import echo_oracle as O
+    cfg = optimized_config()
+    tables = build_tables(cfg)
+    rx = synth_frames(count, cfg, tables.tx_pcm, start=start)
+    t0 = time.perf_counter()
+    O.chain(rx, tables.chirps_f32, tables.filters, cfg, n_streams=n_streams, mode="named", keep=("spec_db",))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(cfg, tables, rx_host, budget_s, workers):
+    """The oracle (NumPy/SciPy restatement of the reference chain) on the host: one core on a bounded sample of
+    the GPU batch, then the same chain on `workers` processes, each with its own shard of frames."""
     from oracle import echo_oracle as O
     t0 = time.perf_counter()
     O.chain(rx_host[:32], tables.chirps_f32, tables.filters, cfg, n_streams=32, mode="named")
     per = (time.perf_counter() - t0) / 32
     n = int(max(64, min(len(rx_host), budget_s / per)))
+    n -= n % 64
     t0 = time.perf_counter()
     O.chain(rx_host[:n], tables.chirps_f32, tables.filters, cfg, n_streams=min(n, N_STREAMS), mode="named",
             keep=("spec_db",))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the {len(rx_host)} frames of the GPU batch, oracle/echo_oracle.py chain "
-                      f"(filtfilt, fftconvolve, rfft+mag2db, correlate, first_strong_peak, fusion, Kalman), "
-                      f"{dt:.1f} s on 1 thread"}
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n} of the {len(rx_host)} frames of the GPU batch, oracle/echo_oracle.py chain "
+                     f"(filtfilt, fftconvolve, rfft+mag2db, correlate, first_strong_peak, fusion, Kalman), "
+                     f"{dt:.1f} s on 1 thread"}
+    if workers > 1:
+        per_worker = max(64, int(n / 2) - int(n / 2) % 64)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                                   str(w * per_worker), str(per_worker)], stdout=subprocess.PIPE, text=True)
+                 for w in range(workers)]
+        inner = []
+        for p in procs:
+            text, _ = p.communicate(timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError("CPU-baseline worker failed")
+            inner.append(float(text.strip().splitlines()[-1]))
+        wall = max(inner)
+        out["all_cores"] = {"value": workers * per_worker / wall, "unit": "frames/s", "cores": workers,
+                            "sample": f"{workers} processes x {per_worker} frames, slowest process {wall:.1f} s "
+                                      f"(wall {time.perf_counter() - t0:.1f} s incl. interpreter start-up)"}
+    return out
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        print(_cpu_worker((args.cpu_worker[0], args.cpu_worker[1], 64)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
         # convenience: re-launch under torch.distributed.run as a child process (nothing has touched the GPU yet)
@@ -152,7 +194,7 @@ def main():
             "kernel_ms": kms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds, args.cpu_workers)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
