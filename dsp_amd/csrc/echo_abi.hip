@@ -18,6 +18,8 @@ struct EchoHandle {
     int device = 0;
     bool bodd0 = false;
     BandParams base;                       // sizes, layout and device table pointers
+    bool long_path = false;                // frame too long for one workgroup, or the MAD detector: tiled kernels
+    LongParams lbase;
     // device constant tables
     double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
     float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
@@ -26,6 +28,8 @@ struct EchoHandle {
     double* d_fwd = nullptr;               // IIR forward-pass output
     double* d_y = nullptr;                 // IIR result
     float* d_bandf = nullptr;              // float32 band_sig handed from the band kernel to the spectrum kernel
+    double* d_band = nullptr;              // long path: band_sig
+    double* d_pos = nullptr;               // long path: corr[half:]
     BandRes* d_res = nullptr;
     double* d_fused = nullptr;
     uint8_t* d_vany = nullptr;
@@ -47,8 +51,8 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
-    (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf);
-    h->d_bandf = nullptr;
+    (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf); (void)hipFree(h->d_band); (void)hipFree(h->d_pos);
+    h->d_bandf = nullptr; h->d_band = h->d_pos = nullptr;
     h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
     h->cap_frames = 0;
 }
@@ -63,7 +67,10 @@ int ensure_scratch(EchoHandle* h, int frames) {
     const size_t y_n = (size_t)frames * c.n_bands * c.n_rx;
     if (hipMalloc(reinterpret_cast<void**>(&h->d_fwd), fwd_n * sizeof(double)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_y), y_n * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess ||
+        (!h->long_path && hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess) ||
+        (h->long_path && (hipMalloc(reinterpret_cast<void**>(&h->d_band), y_n * sizeof(double)) != hipSuccess ||
+                          hipMalloc(reinterpret_cast<void**>(&h->d_pos), (size_t)frames * c.n_bands *
+                                    (size_t)(h->lbase.L - h->lbase.half) * sizeof(double)) != hipSuccess)) ||
         hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_vany), (size_t)frames) != hipSuccess) {
@@ -97,7 +104,10 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
     return p;
 }
 
-bool detector_supported(int d) { return d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW; }
+bool detector_supported(const EchoHandle* h) {
+    const int d = h->cfg.detector;
+    return h->long_path ? d == ECHO_DET_MAD : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
+}
 
 }  // namespace
 
@@ -133,10 +143,16 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (const char* m = std::getenv("ECHO_IIR_MODE")) h->iir_mode = std::atoi(m);   // development override
     (void)hipGetDevice(&h->device);
     std::memset(&h->base, 0, sizeof(h->base));
-    if (!plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay, cfg->noise_n,
-                   cfg->detector, cfg->snr_gate_db)) {
-        delete h;
-        return ECHO_ERR_UNSUPPORTED;
+    const bool fits = plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay,
+                                cfg->noise_n, cfg->detector, cfg->snr_gate_db);
+    h->long_path = !fits || cfg->detector == ECHO_DET_MAD;
+    std::memset(&h->lbase, 0, sizeof(h->lbase));
+    if (h->long_path) {
+        if (!plan_long(h->lbase, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay, cfg->detector)) {
+            delete h;
+            return ECHO_ERR_UNSUPPORTED;
+        }
+        h->max_chunk = std::min(4096, 65535 / cfg->n_bands);
     }
     const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
     h->bodd0 = true;
@@ -146,7 +162,8 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     for (int j = 0; j < nb; ++j)
         if (cfg->a[j * nc] != 1.0) { delete h; return ECHO_ERR_INVALID; }   // tables must be a0-normalised
     HostTables t;
-    build_tables(t, h->base, cfg->taps, cfg->chirps);
+    if (h->long_path) build_coef_tables(t, nb, cfg->n_taps, cfg->n_chirp, cfg->taps, cfg->chirps);
+    else build_tables(t, h->base, cfg->taps, cfg->chirps);
     int rc = ECHO_OK;
     auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
     up(dev_upload(&h->d_b, cfg->b, (size_t)nb * nc));
@@ -154,14 +171,19 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     up(dev_upload(&h->d_zi, cfg->zi, (size_t)nb * (nc - 1)));
     up(dev_upload(&h->d_taps_rev, t.taps_rev.data(), t.taps_rev.size()));
     up(dev_upload(&h->d_chirp, t.chirp.data(), t.chirp.size()));
-    up(dev_upload(&h->d_bw, t.bw.data(), t.bw.size()));
-    up(dev_upload(&h->d_bhat, t.bhat.data(), t.bhat.size()));
-    up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
-    up(dev_upload(&h->d_post, t.post.data(), t.post.size()));
-    if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
+    if (!h->long_path) {
+        up(dev_upload(&h->d_bw, t.bw.data(), t.bw.size()));
+        up(dev_upload(&h->d_bhat, t.bhat.data(), t.bhat.size()));
+        up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
+        up(dev_upload(&h->d_post, t.post.data(), t.post.size()));
+        if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
+    } else if (rc == ECHO_OK) {
+        rc = long_kernels_prepare(h->lbase);
+    }
     if (rc != ECHO_OK) { echo_destroy(h); return rc; }
     h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
+    h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
     *out = h;
@@ -218,6 +240,14 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
 
 int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream) {
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
+    if (h->long_path) {
+        for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+            LongParams q = h->lbase;
+            q.fir_rx = 1; q.rx_in = rx + (size_t)f0 * q.N; q.band_out = out + (size_t)f0 * q.nb * q.N;
+            if (int rc = launch_long_fir(q, std::min(h->max_chunk, B - f0), static_cast<hipStream_t>(stream))) return rc;
+        }
+        return ECHO_OK;
+    }
     BandParams p = h->base;
     p.mode = MODE_RX_FIR; p.do_corr = 0; p.rx_in = rx; p.band_out = out;
     return launch_band(p, B, static_cast<hipStream_t>(stream));
@@ -233,6 +263,13 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
         const size_t o = (size_t)f0 * h->cfg.n_bands * h->cfg.n_rx;
         rc = run_iir(h, rx + (size_t)f0 * h->cfg.n_rx, h->d_y, n, s);
         if (rc) return rc;
+        if (h->long_path) {
+            LongParams q = h->lbase;
+            q.fir_rx = 0; q.d_in = h->d_y; q.band_out = band_sig + o;
+            rc = launch_long_fir(q, n, s);
+            if (rc) return rc;
+            continue;
+        }
         BandParams p = h->base;
         p.mode = MODE_Y_FIR; p.do_corr = 0; p.d_in = h->d_y; p.band_out = band_sig + o;
         rc = launch_band(p, n, s);
@@ -243,6 +280,7 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
 
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
     if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
+    if (h->long_path) return ECHO_ERR_UNSUPPORTED;
     BandParams p = h->base;
     p.spec_db = db ? 1 : 0; p.specd_in = band_sig; p.spec_out = spec;
     return launch_spec(p, B, static_cast<hipStream_t>(stream));
@@ -255,6 +293,15 @@ int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
 
 int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream) {
     if (!h || !band_sig || !corr || B < 0) return ECHO_ERR_INVALID;
+    if (h->long_path) {
+        for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+            LongParams q = h->lbase;
+            q.band_in = band_sig + (size_t)f0 * q.nb * q.N; q.corr_out = corr + (size_t)f0 * q.nb * q.L;
+            q.k_begin = 0; q.corr_k0 = 0; q.corr_stride = q.L;
+            if (int rc = launch_long_corr(q, std::min(h->max_chunk, B - f0), static_cast<hipStream_t>(stream))) return rc;
+        }
+        return ECHO_OK;
+    }
     BandParams p = h->base;
     p.mode = MODE_BAND; p.do_corr = 1; p.d_in = band_sig; p.corr_io = corr; p.res_out = nullptr;
     return launch_band(p, B, static_cast<hipStream_t>(stream));
@@ -263,17 +310,24 @@ int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, v
 int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db, double* amplitude,
                            int B, void* stream) {
     if (!h || !corr || !peak_idx || !snr_db || B < 0) return ECHO_ERR_INVALID;
-    if (!detector_supported(h->cfg.detector)) return ECHO_ERR_UNSUPPORTED;
+    if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands;
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
         const int n = std::min(h->max_chunk, B - f0);
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
-        BandParams p = h->base;
-        p.mode = MODE_CORR; p.do_corr = 1; p.write_corr_mutated = 1;
-        p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->d_res;
-        rc = launch_band(p, n, s);
+        if (h->long_path) {
+            LongParams q = h->lbase;
+            q.det_io = corr + (size_t)f0 * nb * q.L; q.det_stride = q.L; q.det_off = q.half; q.write_mutated = 1;
+            q.res_out = h->d_res;
+            rc = launch_long_detect(q, n, s);
+        } else {
+            BandParams p = h->base;
+            p.mode = MODE_CORR; p.do_corr = 1; p.write_corr_mutated = 1;
+            p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->d_res;
+            rc = launch_band(p, n, s);
+        }
         if (rc) return rc;
         rc = launch_unpack_res(h->d_res, peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb,
                                amplitude ? amplitude + (size_t)f0 * nb : nullptr, n * nb, s);
@@ -319,7 +373,8 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     const bool kal = kalman_x || kalman_p || kalman_init;
     if (kal && (!kalman_x || !kalman_p || !kalman_init || n_streams < 1 || B % n_streams != 0)) return ECHO_ERR_INVALID;
-    if (!detector_supported(h->cfg.detector)) return ECHO_ERR_UNSUPPORTED;
+    if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
+    if (h->long_path && spec_db) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands, N = h->cfg.n_rx;
     // frames are processed in passes of at most max_chunk; with a Kalman state each pass must hold whole
@@ -339,12 +394,26 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
         if (rc) return rc;
         if (prof) (void)hipEventRecord(ev[1], s);
-        BandParams p = h->base;
-        p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
-        p.d_in = h->d_y; p.res_out = h->d_res;
-        p.bandf_out = spec_db ? h->d_bandf : nullptr;
-        rc = launch_band(p, n, s);
-        if (rc) return rc;
+        if (h->long_path) {
+            LongParams q = h->lbase;
+            q.fir_rx = 0; q.d_in = h->d_y; q.band_out = h->d_band;
+            rc = launch_long_fir(q, n, s);
+            if (rc) return rc;
+            q.band_in = h->d_band; q.corr_out = h->d_pos;
+            q.k_begin = std::min(q.half + q.min_delay, q.L - 1); q.corr_k0 = q.half; q.corr_stride = q.L - q.half;
+            rc = launch_long_corr(q, n, s);
+            if (rc) return rc;
+            q.det_io = h->d_pos; q.det_stride = q.L - q.half; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
+            rc = launch_long_detect(q, n, s);
+            if (rc) return rc;
+        } else {
+            BandParams p = h->base;
+            p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
+            p.d_in = h->d_y; p.res_out = h->d_res;
+            p.bandf_out = spec_db ? h->d_bandf : nullptr;
+            rc = launch_band(p, n, s);
+            if (rc) return rc;
+        }
         if (prof) (void)hipEventRecord(ev[2], s);
         if (spec_db) {
             BandParams q = h->base;

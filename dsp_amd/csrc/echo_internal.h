@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "band_phases.h"
+#include "long_phases.h"
 
 namespace echo {
 
@@ -42,6 +43,10 @@ int launch_iir_quad(const IirParams& p, int ncoef, hipStream_t s);             /
 int launch_band(const BandParams& p, int B, hipStream_t s);
 int band_kernel_prepare(int smem_bytes, int spec_smem_bytes);
 int launch_spec(const BandParams& p, int B, hipStream_t s);
+int long_kernels_prepare(const LongParams& p);
+int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <= 65535 per launch
+int launch_long_corr(const LongParams& p, int B, hipStream_t s);
+int launch_long_detect(const LongParams& p, int B, hipStream_t s);
 int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, BandRes* res, int n, hipStream_t s);
 int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s);
 int launch_fuse(const FuseParams& p, hipStream_t s);

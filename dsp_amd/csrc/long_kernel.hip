@@ -1,0 +1,76 @@
+// Kernels of the long-frame path (long_phases.h): tiled FIR, tiled matched filter, median/MAD detector.
+// Compiled with -ffp-contract=off: the detector threshold med + 6*mad is a rounded product and a rounded sum, as
+// NumPy evaluates it (airSonar.py:111-113); the sliding dot products use explicit fma().
+#include <hip/hip_runtime.h>
+
+#include "../../include/echo_hip.h"
+#include "echo_internal.h"
+#include "long_phases.h"
+
+namespace echo {
+
+__global__ __launch_bounds__(kLFirNT) void long_fir_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, tile = blockIdx.x, blk = blockIdx.y;
+    ph_lfir_load(tid, kLFirNT, tile, blk, p, smem);
+    __syncthreads();
+    ph_lfir_run(tid, kLFirNT, tile, blk, p, smem);
+}
+
+__global__ __launch_bounds__(kLCorrNT) void long_corr_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, tile = blockIdx.x, blk = blockIdx.y;
+    ph_lcorr_load(tid, kLCorrNT, blk, p, smem);
+    __syncthreads();
+    ph_lcorr_run(tid, kLCorrNT, tile, blk, p, smem);
+}
+
+__global__ __launch_bounds__(kLDetNT) void long_detect_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_LDET_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kLDetNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP; }
+
+int long_kernels_prepare(const LongParams& p) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(long_fir_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.fir_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.corr_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(long_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.det_smem) != hipSuccess)
+        return ECHO_ERR_HIP;
+    return ECHO_OK;
+}
+
+// grid.y carries the (frame, band) index and is limited to 65535: callers pass at most that many blocks per launch
+int launch_long_fir(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int nblk = B * p.nb;
+    if (nblk > 65535) return ECHO_ERR_INVALID;
+    const int tiles = (p.N + kLFirNT * kR - 1) / (kLFirNT * kR);
+    hipLaunchKernelGGL(long_fir_kernel, dim3(tiles, nblk), dim3(kLFirNT), p.fir_smem, s, p);
+    return ok();
+}
+
+int launch_long_corr(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int nblk = B * p.nb;
+    if (nblk > 65535 || p.k_begin < 0 || p.k_begin >= p.L) return ECHO_ERR_INVALID;
+    const int tiles = (p.L - p.k_begin + kLCorrNT * kR - 1) / (kLCorrNT * kR);
+    hipLaunchKernelGGL(long_corr_kernel, dim3(tiles, nblk), dim3(kLCorrNT), p.corr_smem, s, p);
+    return ok();
+}
+
+int launch_long_detect(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(long_detect_kernel, dim3(B * p.nb), dim3(kLDetNT), p.det_smem, s, p);
+    return ok();
+}
+
+}  // namespace echo

@@ -1,0 +1,284 @@
+// Long-frame path: the same chain as band_phases.h for frames that do not fit one workgroup's LDS, and the
+// median/MAD first-crossing detector of the original parameter set.  Three kernels, each tiled over outputs:
+//   FIR 'same'            y or rx  -> band_sig (float64, global)               airSonar.py:98-101
+//   matched filter        band_sig -> corr[k_begin:] (float64, global)        airSonar.py:224
+//   first_strong_peak     pos = corr[half:] -> first index above med + 6 MAD  airSonar.py:104-117
+// Written as barrier-separated phases of (tid, nt) like band_phases.h, so a host build can run them thread by
+// thread.  Plain C++ apart from the two LDS atomics.
+#pragma once
+#include "band_phases.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ECHO_LDS_ADD(p, v) atomicAdd((p), (v))
+#define ECHO_LDS_MIN(p, v) atomicMin((p), (v))
+#else
+#define ECHO_LDS_ADD(p, v) (*(p) += (v))
+#define ECHO_LDS_MIN(p, v) (*(p) = (v) < *(p) ? (v) : *(p))
+#endif
+
+namespace echo {
+
+constexpr int kLFirNT = 256;                   // threads per FIR workgroup: kLFirNT*kR outputs per tile
+constexpr int kLCorrNT = 768;                  // threads per correlation workgroup: kLCorrNT*kR outputs per tile
+constexpr int kLDetNT = 1024;                  // threads per detector workgroup
+constexpr int kLPad = 64 * kR + 2 * kR;        // zero margin either side of the LDS signal: one wavefront's spread of
+                                               // first outputs (64*kR) plus the window prefetch (2*kR)
+
+struct LongParams {
+    int N, M, L, half, nb, K, min_delay, detector;
+    int kgroups, mgroups, ypad;
+    const double* taps_rev;          // [nb][(kgroups+1)*kR]
+    const double* chirp;             // [nb][(mgroups+1)*kR]
+    // FIR
+    int fir_rx;                      // 1: input is rx float32 [B][N]; 0: input is float64 [B][nb][N]
+    const float* rx_in;
+    const double* d_in;
+    double* band_out;                // [B][nb][N]
+    float* bandf_out;                // optional float32 copy (spectrum input)
+    // matched filter: corr[k], k_begin <= k < L, stored at corr_out[blk*corr_stride + k - corr_k0]
+    const double* band_in;           // [B][nb][N]
+    double* corr_out;
+    int k_begin, corr_k0;
+    long long corr_stride;
+    // detector: pos[q] = det_io[blk*det_stride + det_off + q], 0 <= q < L - half; q < min_delay reads as zero
+    double* det_io;
+    long long det_stride;
+    int det_off, write_mutated;
+    BandRes* res_out;                // [B][nb]
+    // LDS sizes
+    int fir_smem, corr_smem, det_smem;
+};
+
+struct DetMisc {                     // detector scalars in LDS
+    unsigned long long prefix;
+    double med, mad, lo, hi;
+    int rank, shift, first, pad;
+};
+
+inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay, int detector) {
+    p.N = N; p.M = M; p.L = N + M - 1; p.half = p.L / 2; p.nb = nb; p.K = K;
+    p.min_delay = min_delay; p.detector = detector;
+    p.kgroups = (K + kR - 1) / kR; p.mgroups = (M + kR - 1) / kR;
+    p.ypad = K - 1 - (K - 1) / 2;
+    if (N < 4 || M < 1 || K < 1) return false;
+    p.fir_smem = (kLFirNT * kR + (p.kgroups + 1) * kR) * 8 + (p.kgroups + 1) * kR * 8;
+    p.corr_smem = (N + 2 * kLPad) * 8 + (p.mgroups + 1) * kR * 8;
+    const int npos = p.L - p.half;
+    p.det_smem = ((npos + 1) & ~1) * 8 + 256 * 4 + (int)sizeof(DetMisc);
+    return p.fir_smem <= 160 * 1024 && p.corr_smem <= 160 * 1024 && p.det_smem <= 160 * 1024;
+}
+
+// ---------------------------------------------------------------- FIR 'same', one tile of kLFirNT*kR outputs
+// LDS: double in[nt*kR + (kgroups+1)*kR] holding input[t0 - ypad + i], then the reversed taps.
+ECHO_HD void ph_lfir_load(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem) {
+    double* in = reinterpret_cast<double*>(smem);
+    const int len = nt * kR + (p.kgroups + 1) * kR;
+    double* ct = in + len;
+    const int band = blk % p.nb, frame = blk / p.nb;
+    const int t0 = tile * nt * kR;
+    for (int i = tid; i < len; i += nt) {
+        const int n = t0 + i - p.ypad;
+        double v = 0.0;
+        if (n >= 0 && n < p.N) v = p.fir_rx ? (double)p.rx_in[(size_t)frame * p.N + n] : p.d_in[(size_t)blk * p.N + n];
+        in[i] = v;
+    }
+    const int nc = (p.kgroups + 1) * kR;
+    for (int i = tid; i < nc; i += nt) ct[i] = p.taps_rev[(size_t)band * nc + i];
+}
+
+ECHO_HD void ph_lfir_run(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem) {
+    const double* in = reinterpret_cast<const double*>(smem);
+    const double* ct = in + nt * kR + (p.kgroups + 1) * kR;
+    const int n0 = tile * nt * kR + tid * kR;
+    if (n0 >= p.N) return;
+    double acc[kR];
+    sliding_dot(in + tid * kR, ct, p.kgroups, acc);
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        const int n = n0 + r;
+        if (n < p.N) {
+            if (p.band_out) p.band_out[(size_t)blk * p.N + n] = acc[r];
+            if (p.bandf_out) p.bandf_out[(size_t)blk * p.N + n] = (float)acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- matched filter, one tile of kLCorrNT*kR lags
+// corr[k] = sum_j chirp[j] * band_sig[k - (M-1) + j].  LDS: double sig[kLPad + N + kLPad] (zero margins), then the
+// chirp.  Each wavefront trims the tap range to the taps that overlap the frame for at least one of its lanes;
+// the margins absorb the lanes whose own overlap is shorter.
+ECHO_HD void ph_lcorr_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    double* sig = reinterpret_cast<double*>(smem);
+    const int len = p.N + 2 * kLPad;
+    double* cc = sig + len;
+    const int band = blk % p.nb;
+    for (int i = tid; i < len; i += nt) {
+        const int n = i - kLPad;
+        sig[i] = (n >= 0 && n < p.N) ? p.band_in[(size_t)blk * p.N + n] : 0.0;
+    }
+    const int nc = (p.mgroups + 1) * kR;
+    for (int i = tid; i < nc; i += nt) cc[i] = p.chirp[(size_t)band * nc + i];
+}
+
+ECHO_HD void ph_lcorr_run(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem) {
+    const double* sig = reinterpret_cast<const double*>(smem);
+    const double* cc = sig + p.N + 2 * kLPad;
+    const int kt0 = p.k_begin + tile * nt * kR;
+    const int kw0 = kt0 + (tid / 64) * 64 * kR;          // first lag of this wavefront
+    const int k0 = kt0 + tid * kR;
+    if (kw0 >= p.L) return;
+    int jlo = (p.M - 1) - (kw0 + 64 * kR - 1);
+    jlo = jlo < 0 ? 0 : (jlo / kR) * kR;
+    int jhi = p.N + (p.M - 1) - kw0;
+    jhi = jhi > p.M ? p.M : jhi;
+    const int ng = (jhi - jlo + kR - 1) / kR;
+    double acc[kR];
+    sliding_dot(sig + kLPad + k0 - (p.M - 1) + jlo, cc + jlo, ng, acc);
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+        const int k = k0 + r;
+        if (k < p.L) p.corr_out[(size_t)blk * p.corr_stride + (k - p.corr_k0)] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------- median/MAD first-crossing detector
+// Order statistics by most-significant-digit radix selection on the order-preserving integer image of a double:
+// eight passes of 8 bits, each a 256-bin LDS histogram of the elements that match the digits fixed so far.
+ECHO_HD unsigned long long ordered_key(double v) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+ECHO_HD double key_value(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    __builtin_memcpy(&v, &u, 8);
+    return v;
+}
+
+ECHO_HD double* det_pos(unsigned char* smem) { return reinterpret_cast<double*>(smem); }
+ECHO_HD int* det_hist(const LongParams& p, unsigned char* smem) {
+    return reinterpret_cast<int*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
+}
+ECHO_HD DetMisc* det_misc(const LongParams& p, unsigned char* smem) {
+    return reinterpret_cast<DetMisc*>(reinterpret_cast<unsigned char*>(det_hist(p, smem)) + 256 * 4);
+}
+
+ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    double* pos = det_pos(smem);
+    const int npos = p.L - p.half;
+    double* src = p.det_io + (size_t)blk * p.det_stride + p.det_off;
+    for (int q = tid; q < npos; q += nt) {
+        double v = 0.0;
+        if (q >= p.min_delay) v = src[q];
+        else if (p.write_mutated) src[q] = 0.0;
+        pos[q] = v;
+    }
+    if (tid == 0) { DetMisc* m = det_misc(p, smem); m->first = 0x7fffffff; m->med = 0.0; m->mad = 0.0; }
+}
+
+// selection of the element of rank `rank` among key(i) = pos[i] (dev == 0) or |pos[i] - med| (dev == 1)
+ECHO_HD void ph_sel_begin(int tid, const LongParams& p, unsigned char* smem, int rank) {
+    if (tid != 0) return;
+    DetMisc* m = det_misc(p, smem);
+    m->prefix = 0; m->rank = rank; m->shift = 56;
+}
+ECHO_HD void ph_sel_zero(int tid, const LongParams& p, unsigned char* smem) {
+    if (tid < 256) det_hist(p, smem)[tid] = 0;
+}
+ECHO_HD void ph_sel_count(int tid, int nt, const LongParams& p, unsigned char* smem, int dev) {
+    const double* pos = det_pos(smem);
+    int* hist = det_hist(p, smem);
+    const DetMisc* m = det_misc(p, smem);
+    const int npos = p.L - p.half, shift = m->shift;
+    const unsigned long long prefix = m->prefix;
+    const double med = m->med;
+    for (int i = tid; i < npos; i += nt) {
+        const double v = dev ? fabs(pos[i] - med) : pos[i];
+        const unsigned long long k = ordered_key(v);
+        const bool match = shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8));
+        if (match) ECHO_LDS_ADD(&hist[(int)((k >> shift) & 255)], 1);
+    }
+}
+ECHO_HD void ph_sel_pick(int tid, const LongParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const int* hist = det_hist(p, smem);
+    DetMisc* m = det_misc(p, smem);
+    int cum = 0, d = 0;
+    for (; d < 255; ++d) {
+        if (cum + hist[d] > m->rank) break;
+        cum += hist[d];
+    }
+    m->rank -= cum;
+    m->prefix |= (unsigned long long)d << m->shift;
+    m->shift -= 8;
+}
+// after the eighth pass m->prefix is the key of the wanted element
+ECHO_HD void ph_sel_store(int tid, const LongParams& p, unsigned char* smem, int which) {
+    if (tid != 0) return;
+    DetMisc* m = det_misc(p, smem);
+    const double v = key_value(m->prefix);
+    if (which == 0) m->lo = v; else m->hi = v;
+}
+// np.median: the middle element, or the mean of the two middle elements ((a + b) / 2)
+ECHO_HD void ph_ldet_set_med(int tid, const LongParams& p, unsigned char* smem, int two) {
+    if (tid != 0) return;
+    DetMisc* m = det_misc(p, smem);
+    m->med = two ? (m->lo + m->hi) / 2.0 : m->lo;
+}
+ECHO_HD void ph_ldet_set_mad(int tid, const LongParams& p, unsigned char* smem, int two) {
+    if (tid != 0) return;
+    DetMisc* m = det_misc(p, smem);
+    m->mad = (two ? (m->lo + m->hi) / 2.0 : m->lo) + 1e-9;
+}
+ECHO_HD void ph_ldet_cross(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    const double* pos = det_pos(smem);
+    DetMisc* m = det_misc(p, smem);
+    const int npos = p.L - p.half;
+    const double six_mad = 6.0 * m->mad;
+    const double thr = m->med + six_mad;
+    int first = 0x7fffffff;
+    for (int q = tid; q < npos; q += nt)
+        if (pos[q] > thr) { first = q; break; }
+    if (first != 0x7fffffff) ECHO_LDS_MIN(&m->first, first);
+}
+ECHO_HD void ph_ldet_finish(int tid, int blk, const LongParams& p, unsigned char* smem) {
+    if (tid != 0 || !p.res_out) return;
+    const DetMisc* m = det_misc(p, smem);
+    BandRes r;
+    r.snr_db = 0.0; r.amplitude = 0.0; r.pad = 0;
+    r.peak_idx = m->first == 0x7fffffff ? -1 : m->first;
+    p.res_out[blk] = r;
+}
+
+// The barrier-separated sequence of one detector workgroup; SYNC is __syncthreads() on the device and the end of a
+// for-all-threads loop on the host.
+#define ECHO_LDET_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                               \
+    do {                                                                                                \
+        const int npos_ = (p).L - (p).half;                                                             \
+        if (npos_ <= (p).min_delay) {                                                                   \
+            PHASE(if (tid == 0 && (p).res_out) { BandRes r_; r_.snr_db = 0.0; r_.amplitude = 0.0;       \
+                                                  r_.pad = 0; r_.peak_idx = -1; (p).res_out[blk] = r_; }) \
+            break;                                                                                      \
+        }                                                                                               \
+        const int two_ = (npos_ % 2 == 0) ? 1 : 0;                                                      \
+        PHASE(ph_ldet_load(tid, nt, blk, p, smem)) SYNC                                                 \
+        for (int dev_ = 0; dev_ < 2; ++dev_) {                                                          \
+            for (int w_ = 0; w_ <= two_; ++w_) {                                                        \
+                const int rank_ = two_ ? npos_ / 2 - 1 + w_ : npos_ / 2;                                \
+                PHASE(ph_sel_begin(tid, p, smem, rank_)) SYNC                                           \
+                for (int pass_ = 0; pass_ < 8; ++pass_) {                                               \
+                    PHASE(ph_sel_zero(tid, p, smem)) SYNC                                               \
+                    PHASE(ph_sel_count(tid, nt, p, smem, dev_)) SYNC                                    \
+                    PHASE(ph_sel_pick(tid, p, smem)) SYNC                                               \
+                }                                                                                       \
+                PHASE(ph_sel_store(tid, p, smem, w_)) SYNC                                              \
+            }                                                                                           \
+            PHASE(if (dev_ == 0) ph_ldet_set_med(tid, p, smem, two_);                                   \
+                  else ph_ldet_set_mad(tid, p, smem, two_)) SYNC                                        \
+        }                                                                                               \
+        PHASE(ph_ldet_cross(tid, nt, p, smem)) SYNC                                                     \
+        PHASE(ph_ldet_finish(tid, blk, p, smem))                                                        \
+    } while (0)
+
+}  // namespace echo

@@ -85,16 +85,21 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     return off <= 160 * 1024;
 }
 
-inline void build_tables(HostTables& t, const BandParams& p, const double* taps, const double* chirps) {
-    const double pi = 3.14159265358979323846;
-    const int nb = p.nb, K = p.K, M = p.M, n2 = p.n2, N = p.N;
-    const int kn = (p.kgroups + 1) * kR, mn = (p.mgroups + 1) * kR;
+// Reversed taps and chirps, zero-padded to whole groups of kR plus one extra zero group.
+inline void build_coef_tables(HostTables& t, int nb, int K, int M, const double* taps, const double* chirps) {
+    const int kn = (ceil_div(K, kR) + 1) * kR, mn = (ceil_div(M, kR) + 1) * kR;
     t.taps_rev.assign((size_t)nb * kn, 0.0);
     t.chirp.assign((size_t)nb * mn, 0.0);
     for (int b = 0; b < nb; ++b) {
         for (int j = 0; j < K; ++j) t.taps_rev[(size_t)b * kn + j] = taps[(size_t)b * K + (K - 1 - j)];
         for (int j = 0; j < M; ++j) t.chirp[(size_t)b * mn + j] = chirps[(size_t)b * M + j];
     }
+}
+
+inline void build_tables(HostTables& t, const BandParams& p, const double* taps, const double* chirps) {
+    const double pi = 3.14159265358979323846;
+    const int n2 = p.n2, N = p.N;
+    build_coef_tables(t, p.nb, p.K, p.M, taps, chirps);
     // Bluestein chirp w[n] = exp(-i*pi*n^2/n2); n^2 reduced mod 2*n2 in integers so the phase stays exact
     std::vector<std::complex<double>> w(n2);
     t.bw.assign((size_t)align_up(n2, 2), mk(0, 0));

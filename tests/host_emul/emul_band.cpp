@@ -3,6 +3,7 @@
 // checked against the oracle on a machine without a GPU; the product never loads it.
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../dsp_amd/csrc/tables.h"
@@ -67,5 +68,58 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
         if (amp) amp[i] = res[i].amplitude;
         if (peak) peak[i] = res[i].peak_idx;
     }
+    return 0;
+}
+
+// Long-frame path (dsp_amd/csrc/long_phases.h): FIR tiles -> matched-filter tiles -> median/MAD detector.
+// y: [B][nb][N] zero-phase IIR output.  band_out [B][nb][N]; corr_out [B][nb][L] (lags below k_begin are left
+// untouched); peak [B][nb].  With corr_in non-null the FIR and correlation are skipped and the detector runs on
+// corr_in in place (blind zone written back), like a direct first_strong_peak call.
+#include "../../dsp_amd/csrc/long_phases.h"
+
+extern "C" int emul_long(int N, int M, int K, int nb, int min_delay, int detector, const double* taps,
+                         const double* chirps, const double* y, double* corr_in, int B, int k_begin,
+                         double* band_out, double* corr_out, int* peak) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, min_delay, detector)) return -2;
+    HostTables t;
+    build_coef_tables(t, nb, K, M, taps, chirps);
+    p.taps_rev = t.taps_rev.data(); p.chirp = t.chirp.data();
+    std::vector<BandRes> res((size_t)B * nb);
+    p.res_out = res.data();
+    const int smem_bytes = std::max(p.fir_smem, std::max(p.corr_smem, p.det_smem));
+    std::vector<unsigned char> smem(smem_bytes);
+    unsigned char* s = smem.data();
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        if (!corr_in) {
+            p.fir_rx = 0; p.d_in = y; p.band_out = band_out;
+            int nt = kLFirNT;
+            const int ftiles = (N + nt * kR - 1) / (nt * kR);
+            for (int tile = 0; tile < ftiles; ++tile) {
+                std::memset(s, 0xff, smem.size());
+                PHASE(ph_lfir_load(tid, nt, tile, blk, p, s));
+                PHASE(ph_lfir_run(tid, nt, tile, blk, p, s));
+            }
+            p.band_in = band_out; p.corr_out = corr_out; p.k_begin = k_begin; p.corr_k0 = 0; p.corr_stride = p.L;
+            nt = kLCorrNT;
+            const int ctiles = (p.L - k_begin + nt * kR - 1) / (nt * kR);
+            for (int tile = 0; tile < ctiles; ++tile) {
+                std::memset(s, 0xff, smem.size());
+                PHASE(ph_lcorr_load(tid, nt, blk, p, s));
+                PHASE(ph_lcorr_run(tid, nt, tile, blk, p, s));
+            }
+        }
+        p.det_io = corr_in ? corr_in : corr_out; p.det_stride = p.L; p.det_off = p.half;
+        p.write_mutated = corr_in ? 1 : 0;
+        const int nt = kLDetNT;
+        std::memset(s, 0xff, smem.size());
+        ECHO_LDET_SEQUENCE(PHASE, SYNC, p, s, blk, nt);
+    }
+#undef PHASE
+#undef SYNC
+    for (size_t i = 0; i < res.size(); ++i) peak[i] = res[i].peak_idx;
     return 0;
 }

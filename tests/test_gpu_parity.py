@@ -232,3 +232,49 @@ def test_dropin_function_surface(gold_default, eng_default):
 
 def O_kalman_two(a, b):
     k = O.ScalarKalman(); k.update(a); return k.update(b)
+
+
+def test_original_variant_goldens_and_oracle(gold_original):
+    """airSonar.py parameters (FS 44100, N = 8820, M = 4410, IIR order 8, FIR 101, median/MAD first-crossing detector,
+    mean fusion): the long-frame kernels.  scipy.signal.correlate takes its FFT method at these sizes and transforms
+    the float32 chirp in single precision, so the reference correlation carries ~1e-8 of its maximum; the kernel
+    sums in float64, hence the 1e-7 bound on corr and exact equality on everything derived from indices."""
+    g = gold_original
+    cfg = C.original_config()
+    e = _engine(cfg)
+    from dsp_amd.engine import BatchedKalman
+    rx = rx_from_i16(g["rx_i16"])
+    rec, spec = e.chain(rx, n_streams=1, kalman=BatchedKalman(e, 1), want_spectra=False)
+    r = _rec(rec)
+    assert spec is None
+    assert np.array_equal(r["peak_idx"], g["peak_idx"])
+    valid = ((r["valid_mask"][:, None] >> np.arange(3)) & 1).astype(bool)
+    assert np.array_equal(valid, g["valid"])
+    v = g["valid"]
+    np.testing.assert_allclose(r["dist"][v], g["distance"][v], rtol=RTOL)
+    va = g["valid_any"]
+    np.testing.assert_allclose(r["fused_dist"][va], g["fused_dist"][va], rtol=RTOL)
+    np.testing.assert_allclose(r["kalman"], g["kalman"], rtol=RTOL, atol=1e-7)
+    # stages of frame 0
+    band = e.bandpass_bank(rx[:1])
+    ref = g["stage_band_sig0"]
+    assert (np.abs(band[0].cpu().numpy() - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-12
+    corr = e.correlate(band)
+    ref = g["stage_corr0"]
+    assert (np.abs(corr[0].cpu().numpy() - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-7
+    c = torch.from_numpy(ref.copy()[None]).to(band.device)
+    peak, snr, _ = e.first_strong_peak(c)
+    assert np.array_equal(peak[0].cpu().numpy(), g["peak_idx"][0])
+    want = ref.copy(); want[:, cfg.half:cfg.half + cfg.min_delay] = 0
+    assert np.array_equal(c[0].cpu().numpy(), want)
+    # 96 synthetic frames against the oracle: indices exact
+    t = build_tables(cfg)
+    rxs = synth_frames(96, cfg, t.tx_pcm)
+    o = O.chain(rxs, t.chirps_f32, t.filters, cfg, n_streams=4, mode="named")
+    rec, _ = e.chain(rxs, n_streams=4, kalman=BatchedKalman(e, 4), want_spectra=False)
+    r = _rec(rec)
+    assert np.array_equal(r["peak_idx"], o["peak_idx"])
+    v = o["valid"]
+    np.testing.assert_allclose(r["dist"][v], o["distance"][v], rtol=RTOL)
+    np.testing.assert_allclose(r["kalman"], o["kalman"], rtol=RTOL, atol=1e-7)
+    e.close()

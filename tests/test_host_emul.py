@@ -88,3 +88,39 @@ def test_emulated_realtime_variant(emul, gold_realtime):
     assert np.array_equal(r["peak"], g["peak_idx"][:6])
     np.testing.assert_allclose(r["snr"], g["snr_db"][:6], rtol=1e-12)
     np.testing.assert_allclose(r["amp"], g["amplitude"][:6], rtol=1e-13)
+
+
+def test_emulated_long_frame_path(emul, gold_original):
+    """Original parameter set (airSonar.py: N = 8820, M = 4410, FIR 101, MAD first-crossing detector): tiled FIR,
+    tiled matched filter and radix-select medians, thread by thread on the host, against the goldens."""
+    g = gold_original
+    cfg = C.original_config()
+    t = build_tables(cfg)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_long.argtypes = [I] * 6 + [P, P, P, P, I, I, P, P, P]
+    rx = rx_from_i16(g["rx_i16"])
+    B, nb, N, L = len(rx), cfg.n_bands, cfg.n_rx, cfg.n_corr
+    y = np.ascontiguousarray(np.stack([[filtfilt(f[0], f[1], x) for f in t.filters] for x in rx]))
+    taps = np.ascontiguousarray(t.taps); chirps = np.ascontiguousarray(t.chirps)
+    args = (N, cfg.n_chirp, cfg.FIR_TAPS, nb, cfg.min_delay, cfg.DETECTOR, _ptr(taps), _ptr(chirps))
+    # frame 0, every lag: band_sig and the full correlation against scipy's (FFT-method) values
+    band = np.zeros((1, nb, N)); corr = np.zeros((1, nb, L)); peak = np.zeros((1, nb), np.int32)
+    assert emul.emul_long(*args, _ptr(y[:1]), None, 1, 0, _ptr(band), _ptr(corr), _ptr(peak)) == 0
+    # scipy.signal.correlate takes the FFT method at these sizes and transforms the float32 chirp in single
+    # precision, so the reference correlation itself carries ~1e-8 of its maximum; the kernel sums in float64
+    for got, ref, tol in ((band[0], g["stage_band_sig0"], 1e-12), (corr[0], g["stage_corr0"], 1e-7)):
+        scale = np.abs(ref).max(axis=-1, keepdims=True)
+        assert (np.abs(got - ref) / scale).max() <= tol
+    assert np.array_equal(peak[0], g["peak_idx"][0])
+    # all frames the way the chain runs them: only the lags the detector reads
+    band = np.zeros((B, nb, N)); corr = np.zeros((B, nb, L)); peak = np.zeros((B, nb), np.int32)
+    k_begin = cfg.half + cfg.min_delay
+    assert emul.emul_long(*args, _ptr(y), None, B, k_begin, _ptr(band), _ptr(corr), _ptr(peak)) == 0
+    assert np.array_equal(peak, g["peak_idx"])
+    # direct first_strong_peak on a given correlation: same index, blind zone written back
+    c0 = g["stage_corr0"].copy()[None]
+    peak = np.zeros((1, nb), np.int32)
+    assert emul.emul_long(*args, None, _ptr(c0), 1, 0, None, None, _ptr(peak)) == 0
+    assert np.array_equal(peak[0], g["peak_idx"][0])
+    want = g["stage_corr0"].copy(); want[:, cfg.half:cfg.half + cfg.min_delay] = 0
+    assert np.array_equal(c0[0], want)
