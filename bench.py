@@ -22,7 +22,6 @@ sys.path.insert(0, ROOT)
 
 FRAMES_PER_STEP = 4096          # BASELINE.json configs[1]
 N_STREAMS = 64                  # 64 streams x 64 time steps per batch for the Kalman stage
-ALGO_BYTES_PER_FRAME = 42892    # rx 4282*4 in + 3 dB spectra 3*2142*4 out + 60-B result record
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
 
 
@@ -38,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
                     help="internal: run the CPU oracle on one frame shard and print the seconds taken")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
+    ap.add_argument("--workload", choices=("optimized", "original", "realtime"), default="optimized",
+                    help="parameter set; the headline line is 'optimized' (airSonar_optimized.py), the others are "
+                         "secondary measurements of the variants (airSonar.py, realtime_sonar.py)")
     return ap.parse_args()
 
 
@@ -113,7 +115,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from dsp_amd.config import optimized_config
+    from dsp_amd.config import optimized_config, original_config, realtime_config
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.synth import synth_frames
 
@@ -123,7 +125,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = optimized_config()
+    cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config}[args.workload]()
     eng = EchoEngine(cfg, dev)
     B = args.frames
     rx_host = synth_frames(B, cfg, eng.tables.tx_pcm, start=rank * B)
@@ -131,7 +133,7 @@ def main():
     S = N_STREAMS if B % N_STREAMS == 0 else 1
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
-    want_spec = not args.no_spectra
+    want_spec = not args.no_spectra and args.workload != "original"     # no spectrum kernel for 8820-sample frames yet
     rec = torch.empty((B, 64), dtype=torch.uint8, device=dev)
     spec = torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
     gathered = torch.empty((world * B, 64), dtype=torch.uint8, device=dev) if world > 1 else None
@@ -165,14 +167,14 @@ def main():
 
     if rank == 0:
         frames = world * B * args.steps
-        bytes_per_frame = ALGO_BYTES_PER_FRAME if want_spec else 17188
+        bytes_per_frame = cfg.n_rx * 4 + 60 + (cfg.n_bands * cfg.n_bins * 4 if want_spec else 0)   # 42,892 for the headline
         band_s = kms["band"] / 1e3
         achieved = bytes_per_frame * B / band_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_band_kernel.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") if args.workload == "optimized" and B == FRAMES_PER_STEP else None
             except Exception:
                 traffic = None
         out = {
@@ -180,8 +182,10 @@ def main():
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {B} synthetic rx frames per GPU per step, 3 bands, N=4282, M=275, "
-                                   "IIR order 6 (filtfilt) + FIR 61, rfft(4282) dB spectra "
+            "config": {"workload": (f"configs[1]: " if args.workload == "optimized" else f"variant '{args.workload}': ")
+                                   + f"{B} synthetic rx frames per GPU per step, {cfg.n_bands} bands, N={cfg.n_rx}, "
+                                   f"M={cfg.n_chirp}, IIR order {cfg.IIR_ORDER} (filtfilt) + FIR {cfg.FIR_TAPS}, "
+                                   f"rfft({cfg.n_rx}) dB spectra "
                                    + ("stored" if want_spec else "not stored")
                                    + ", correlate, first_strong_peak, confidence fusion, Kalman over "
                                    f"{S} streams" + (", RCCL all-gather of 64-B result records" if world > 1 else ""),
@@ -193,7 +197,7 @@ def main():
                          "note": "VALU/LDS-bound chain (~13 MFLOP/frame f64+f32): HBM fraction is low by construction"},
             "kernel_ms": kms,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "optimized":
             out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds, args.cpu_workers)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -15,7 +15,8 @@ EXPORTS = [
     "echo_create", "echo_destroy", "echo_reserve", "echo_strerror", "echo_version",
     "echo_fir_bank", "echo_bandpass_bank", "echo_spectrum", "echo_mag2db", "echo_correlate",
     "echo_first_strong_peak", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
-    "echo_chain", "echo_set_profiling", "echo_last_kernel_ms",
+    "echo_chain", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
+    "echo_set_profiling", "echo_last_kernel_ms",
 ]
 
 
@@ -62,6 +63,9 @@ def load():
     lib.echo_confidence_fuse.argtypes = [P, P, P, P, P, I, P]
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.echo_graph_create.argtypes = [P, P, P, P, P, P, P, I, I, P, C.POINTER(P)]
+    lib.echo_graph_launch.argtypes = [P, P]
+    lib.echo_graph_destroy.argtypes = [P]; lib.echo_graph_destroy.restype = None
     lib.echo_set_profiling.argtypes = [P, I]
     lib.echo_last_kernel_ms.argtypes = [P] + [C.POINTER(C.c_float)] * 4
     for name in EXPORTS:

@@ -437,4 +437,45 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
     return ECHO_OK;
 }
 
+struct EchoGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
+                      double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, EchoGraph** graph) {
+    if (!h || !graph || !stream || B < 1 || B > h->max_chunk) return ECHO_ERR_INVALID;
+    *graph = nullptr;
+    int rc = ensure_scratch(h, B);          // allocate before the capture: nothing inside it may allocate
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool prof = h->prof;
+    h->prof = false;                        // timing events are not part of the recorded work
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->prof = prof; return ECHO_ERR_HIP; }
+    rc = echo_chain(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream);
+    EchoGraph* g = new (std::nothrow) EchoGraph();
+    const hipError_t e = hipStreamEndCapture(s, g ? &g->graph : nullptr);
+    h->prof = prof;
+    if (!g) return ECHO_ERR_NOMEM;
+    if (rc != ECHO_OK || e != hipSuccess || !g->graph) { echo_graph_destroy(g); return rc ? rc : ECHO_ERR_HIP; }
+    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+        echo_graph_destroy(g);
+        return ECHO_ERR_HIP;
+    }
+    *graph = g;
+    return ECHO_OK;
+}
+
+int echo_graph_launch(EchoGraph* g, void* stream) {
+    if (!g || !g->exec) return ECHO_ERR_INVALID;
+    return hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
+}
+
+void echo_graph_destroy(EchoGraph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 }  // extern "C"

@@ -170,6 +170,22 @@ class EchoEngine:
                                        B, S, self._stream()), "echo_chain")
         return out, spec
 
+    def capture_chain(self, rx: torch.Tensor, kalman: "BatchedKalman", want_spectra: bool = False) -> "ChainGraph":
+        """Streaming mode: records one chain call over the device buffer ``rx`` [S, N] (one frame per stream, i.e.
+        one tick of realtime_sonar.py's loop) into a HIP graph.  Per tick, copy the new frames into ``rx`` and call
+        ``graph.launch()``; records (and spectra) land in ``graph.out`` / ``graph.spec``."""
+        assert rx.is_cuda and rx.dtype == torch.float32 and rx.is_contiguous() and rx.shape == (kalman.S, self.cfg.n_rx)
+        S = kalman.S
+        out = self._empty((S, 64), torch.uint8)
+        spec = self._empty((S, self.cfg.n_bands, self.cfg.n_bins), torch.float32) if want_spectra else None
+        side = torch.cuda.Stream(device=self.device)          # capture needs a stream other than the null stream
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        g = C.c_void_p()
+        _lib.check(self.lib.echo_graph_create(self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(kalman.x), _ptr(kalman.p),
+                                              _ptr(kalman.init), S, S, C.c_void_p(side.cuda_stream), C.byref(g)),
+                   "echo_graph_create")
+        return ChainGraph(self, g, rx, out, spec, kalman)
+
     def set_profiling(self, slots: int):
         """Arm HIP-event timing for the next ``slots`` chain calls (0 disarms)."""
         _lib.check(self.lib.echo_set_profiling(self._h, int(slots)), "echo_set_profiling")
@@ -179,6 +195,28 @@ class EchoEngine:
         _lib.check(self.lib.echo_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)),
                    "echo_last_kernel_ms")
         return {"iir": a.value, "band": b.value, "spec": c.value, "fuse": d.value}
+
+
+class ChainGraph:
+    """A recorded chain call (HIP graph) over fixed device buffers; see EchoEngine.capture_chain."""
+
+    def __init__(self, engine, handle, rx, out, spec, kalman):
+        self.engine, self._g, self.rx, self.out, self.spec, self.kalman = engine, handle, rx, out, spec, kalman
+
+    def launch(self):
+        _lib.check(self.engine.lib.echo_graph_launch(self._g, self.engine._stream()), "echo_graph_launch")
+        return self.out
+
+    def close(self):
+        if self._g:
+            self.engine.lib.echo_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def records_to_numpy(rec: torch.Tensor) -> np.ndarray:

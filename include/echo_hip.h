@@ -145,6 +145,19 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
                double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                int B, int n_streams, void* stream);
 
+/* Streaming mode (realtime_sonar.py:300-350: one frame per stream per tick, Kalman state carried between ticks):
+ * echo_graph_create records one echo_chain call with exactly these arguments into a HIP graph (stream capture on
+ * `stream`, which must not be the null stream; nothing executes during the capture).  echo_graph_launch replays it:
+ * per tick the caller refreshes the contents of `rx` (same device buffer) and launches.  The handle's scratch is
+ * reserved for B frames before the capture; B must not exceed one internal pass (16384 frames).  Other calls on the
+ * handle must not run concurrently with a replay (shared scratch). */
+typedef struct EchoGraph EchoGraph;
+int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
+                      double* kalman_x, double* kalman_p, uint8_t* kalman_init,
+                      int B, int n_streams, void* stream, EchoGraph** graph);
+int echo_graph_launch(EchoGraph* graph, void* stream);
+void echo_graph_destroy(EchoGraph* graph);
+
 /* Kernel timing with HIP events recorded on the call's own stream: echo_set_profiling(h, slots) arms the next
  * `slots` echo_chain calls (0 disarms); echo_last_kernel_ms waits for them and returns the average device time
  * in milliseconds of the IIR kernel, the band kernel, the spectrum kernel and the fusion(+Kalman) kernels over the armed calls

@@ -278,3 +278,26 @@ def test_original_variant_goldens_and_oracle(gold_original):
     np.testing.assert_allclose(r["dist"][v], o["distance"][v], rtol=RTOL)
     np.testing.assert_allclose(r["kalman"], o["kalman"], rtol=RTOL, atol=1e-7)
     e.close()
+
+
+def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
+    """realtime_sonar.py streaming mode: one frame per stream per tick through a recorded HIP graph; records must be
+    byte-identical to direct echo_chain calls, tick by tick, with the Kalman state carried across ticks."""
+    from dsp_amd.engine import BatchedKalman
+    cfg = C.realtime_config()
+    e = _engine(cfg)
+    S, T = 32, 10
+    t = build_tables(cfg)
+    frames = torch.from_numpy(synth_frames(S * T, cfg, t.tx_pcm)).to(e.device).reshape(T, S, cfg.n_rx)
+    k_direct, k_graph = BatchedKalman(e, S), BatchedKalman(e, S)
+    rx = torch.empty((S, cfg.n_rx), dtype=torch.float32, device=e.device)
+    g = e.capture_chain(rx, k_graph, want_spectra=True)
+    for tick in range(T):
+        want, want_spec = e.chain(frames[tick], n_streams=S, kalman=k_direct, want_spectra=True)
+        rx.copy_(frames[tick])
+        got = g.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), tick
+        assert torch.equal(g.spec, want_spec), tick
+    assert torch.equal(k_direct.x, k_graph.x) and torch.equal(k_direct.p, k_graph.p)
+    g.close(); e.close()
