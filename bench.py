@@ -128,8 +128,11 @@ def main():
     cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config}[args.workload]()
     eng = EchoEngine(cfg, dev)
     B = args.frames
-    rx_host = synth_frames(B, cfg, eng.tables.tx_pcm, start=rank * B)
+    # batches beyond 4096 frames repeat a 4096-frame pool (the sharded 1M-frame configuration)
+    rx_host = synth_frames(min(B, 4096), cfg, eng.tables.tx_pcm, start=rank * min(B, 4096))
     rx = torch.from_numpy(rx_host).to(dev)
+    if B > 4096:
+        rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
     S = N_STREAMS if B % N_STREAMS == 0 else 1
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
@@ -169,7 +172,8 @@ def main():
         frames = world * B * args.steps
         bytes_per_frame = cfg.n_rx * 4 + 60 + (cfg.n_bands * cfg.n_bins * 4 if want_spec else 0)   # 42,892 for the headline
         band_s = kms["band"] / 1e3
-        achieved = bytes_per_frame * B / band_s / 1e9
+        launch_frames = min(B, 16384)           # echo_chain runs batches beyond 16384 frames in passes of that size
+        achieved = bytes_per_frame * launch_frames / band_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_band_kernel.json")
         if os.path.exists(tpath):
@@ -193,7 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "band_kernel", "kernel_ms": kms["band"],
-                         "algorithmic_bytes_per_launch": bytes_per_frame * B,
+                         "algorithmic_bytes_per_launch": bytes_per_frame * launch_frames,
                          "note": "VALU/LDS-bound chain (~13 MFLOP/frame f64+f32): HBM fraction is low by construction"},
             "kernel_ms": kms,
         }

@@ -301,3 +301,29 @@ def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
         assert torch.equal(g.spec, want_spec), tick
     assert torch.equal(k_direct.x, k_graph.x) and torch.equal(k_direct.p, k_graph.p)
     g.close(); e.close()
+
+
+def test_chain_one_million_frames_periodic_input(eng_default):
+    """Full size of the sharded configuration (1M frames, here on one GPU): the input repeats a 4096-frame pool, so
+    every per-frame field of the records must repeat with period 4096 (internal 16384-frame passes, chunk edges and
+    64-bit offsets included); the Kalman column is checked against the oracle's scalar filter on one stream."""
+    from dsp_amd.engine import BatchedKalman
+    cfg = eng_default.cfg
+    pool = torch.from_numpy(synth_frames(4096, cfg, eng_default.tables.tx_pcm)).to(eng_default.device)
+    reps = 245
+    B = 1_000_000
+    rx = pool.repeat(reps, 1)[:B].contiguous()
+    S = 64
+    rec, _ = eng_default.chain(rx, n_streams=S, kalman=BatchedKalman(eng_default, S), want_spectra=False)
+    del rx
+    r = _rec(rec)
+    first = r[:4096]
+    for name in ("peak_idx", "dist", "conf", "snr_db", "fused_dist", "avg_conf", "valid_mask"):
+        col = r[name]
+        tiled = np.concatenate([first[name]] * reps)[:B]
+        assert np.array_equal(col, tiled), name
+    # stream 0 of the Kalman column: frames 0, 64, 128, ...
+    kf = O.ScalarKalman(cfg.KALMAN_Q, cfg.KALMAN_R)
+    z = r["fused_dist"][0::S][:2000].astype(np.float64)
+    want = np.array([kf.update(v) for v in z])
+    np.testing.assert_allclose(r["kalman"][0::S][:2000], want, rtol=1e-5)
