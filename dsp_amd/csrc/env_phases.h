@@ -1,0 +1,443 @@
+// Envelope branch of _process_band_gpu for the correlation (airSonar_optimized.py:642-654):
+//   corr_envelope, corr_peaks, corr_quality = gpu_envelope_detection(corr, 'hilbert', smooth_window=5)   :431-475
+//   valid_peaks = corr_peaks[corr_peaks >= min_delay]; peak = valid_peaks[argmax(corr_envelope[valid_peaks])]
+//   snr = 10*log10(corr_envelope[peak]^2 / (mean(corr_envelope[:min_delay]^2) + 1e-10))
+// One workgroup per (frame, band), float64 throughout:
+//   analytic signal: only its imaginary part H(x) is transformed (the real part of scipy.signal.hilbert's result is x
+//   up to rounding): X = rfft(x) by a packed half-length complex FFT (gfft.h), Y = -i X on the positive bins,
+//   H(x) = irfft(Y) by one more half-length FFT; envelope = hypot(x, H(x))
+//   uniform_filter1d(size, mode='reflect'); mean, std; find_peaks(height = mean + 2 std, distance = L // 50,
+//   prominence = std): strict local maxima (plateau midpoints), height filter, distance filter by decreasing height,
+//   prominence filter; calculate_signal_quality (:477-490).
+// Phases of (tid, nt) as in band_phases.h; plain C++.
+#pragma once
+#include "gfft.h"
+
+namespace echo {
+
+ECHO_HD int env_lds_add(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    const int o = *p; *p += v; return o;
+#endif
+}
+
+constexpr int kEnvNT = 512;
+constexpr int kEnvMaxKept = 256;
+constexpr int kEnvChunk = 64;          // prominence scan: per-chunk max/min
+
+struct EnvRes {                        // per (frame, band)
+    double snr_db;                     // envelope-path SNR (valid when peak_idx >= 0)
+    double amplitude;                  // max|corr| over every lag (corr is not mutated on the envelope path)
+    double quality;                    // corr_quality
+    int32_t peak_idx;                  // index into corr (full coordinates), -1: no valid envelope peak -> fall back
+    int32_t n_peaks;                   // len(corr_peaks), diagnostic
+};
+
+struct EnvParams {
+    int L, n, nb, min_delay, smooth, distance;
+    GfftPlan plan;
+    const cpx<double>* roots;          // global, plan.nroots
+    const cpx<double>* wn;             // global, n
+    const cpx<double>* wl;             // global, n + 1: exp(-2*pi*i*k/L)
+    const double* corr;                // [B][nb][L] raw correlation
+    double* env_out;                   // optional [B][nb][L] smoothed envelope
+    EnvRes* res_out;                   // [B][nb]
+    int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
+    int aux_cmax, aux_cmin, aux_kept;  // byte offsets inside the auxiliary buffer (state[] sits at 0)
+};
+
+struct EnvMisc {
+    double sum_sm, max_sm, min_sm, sum_x, sum_x2, amp, sum_noise;     // round 1
+    double ss_sm, ss_x, ss_d;                                          // round 2
+    double mean_sm, mean_x, mean_d, std_sm, thr;
+    double best_val;
+    int n_kept, undecided, best_idx, n_final;
+};
+
+inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
+    p.L = L; p.n = L / 2; p.nb = nb; p.min_delay = min_delay; p.smooth = smooth; p.distance = L / 50;
+    if (L % 2 != 0 || L < 8 || smooth < 1 || smooth % 2 == 0 || smooth > 9) return false;
+    if (p.distance < 1) p.distance = 1;
+    if (!gfft_plan(p.plan, p.n)) return false;
+    int off = 0;
+    p.off_buf0 = off; off += p.n * 16;
+    p.off_buf1 = off; off += p.n * 16;
+    p.off_roots = off; off += p.plan.nroots * 16;
+    p.off_misc = off; off += ((int)sizeof(EnvMisc) + 15) & ~15;
+    p.smem_bytes = off;
+    // After the smoothing the buffer that held the raw envelope is reused: first as reduction scratch (7 quantities
+    // x nt partials + fold area), then for the candidate states, the per-chunk extrema and the list of kept peaks.
+    const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
+    int aux = (L + 15) & ~15;
+    p.aux_cmax = aux; aux += ((nchunk + 1) & ~1) * 8;
+    p.aux_cmin = aux; aux += ((nchunk + 1) & ~1) * 8;
+    p.aux_kept = aux; aux += kEnvMaxKept * 4;
+    return off <= 160 * 1024 && p.n * 16 >= (7 * kEnvNT + 7 * 64) * 8 && p.n * 16 >= aux &&
+           L / p.distance + 2 <= kEnvMaxKept;
+}
+
+inline void env_tables(const EnvParams& p, std::vector<cpx<double>>& roots, std::vector<cpx<double>>& wn,
+                       std::vector<cpx<double>>& wl) {
+    gfft_tables(p.plan, roots, wn);
+    const double pi = 3.14159265358979323846;
+    wl.resize(p.n + 1);
+    for (int k = 0; k <= p.n; ++k) {
+        const double a = -2.0 * pi * (double)k / (double)p.L;
+        wl[k] = cpx<double>{cos(a), sin(a)};
+    }
+}
+
+ECHO_HD cpx<double>* env_buf(unsigned char* s, const EnvParams& p, int which) {
+    return reinterpret_cast<cpx<double>*>(s + (which ? p.off_buf1 : p.off_buf0));
+}
+ECHO_HD EnvMisc* env_misc(unsigned char* s, const EnvParams& p) { return reinterpret_cast<EnvMisc*>(s + p.off_misc); }
+
+// -------------------------------------------------------------------------------- Hilbert transform
+ECHO_HD void ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
+    cpx<double>* z = env_buf(smem, p, 0);
+    const double* x = p.corr + (size_t)blk * p.L;
+    for (int m = tid; m < p.n; m += nt) z[m] = cpx<double>{x[2 * m], x[2 * m + 1]};
+    cpx<double>* r = reinterpret_cast<cpx<double>*>(smem + p.off_roots);
+    for (int i = tid; i < p.plan.nroots; i += nt) r[i] = p.roots[i];
+    if (tid == 0) {
+        EnvMisc* m = env_misc(smem, p);
+        m->n_kept = 0; m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0;
+    }
+}
+
+ECHO_HD void ph_env_fft_pass(int tid, int nt, const EnvParams& p, unsigned char* smem, int ps, int src, bool inv) {
+    const cpx<double>* r = reinterpret_cast<const cpx<double>*>(smem + p.off_roots) + p.plan.root_off[ps];
+    gfft_pass<double>(tid, nt, p.plan, ps, env_buf(smem, p, src), env_buf(smem, p, src ^ 1), r, p.wn, inv);
+}
+
+// Z = FFT_n(x[2m] + i x[2m+1]) -> V, the packed spectrum whose inverse half-length transform is
+// H(x)[2m] + i H(x)[2m+1] (times n).  Pair (k, n-k) is owned by one thread.
+ECHO_HD void ph_env_mid(int tid, int nt, const EnvParams& p, unsigned char* smem, int which) {
+    cpx<double>* Z = env_buf(smem, p, which);
+    const int n = p.n;
+    for (int k = tid; k <= n / 2; k += nt) {
+        if (k == 0) { Z[0] = cpx<double>{0.0, 0.0}; continue; }
+        const int kc = n - k;
+        const cpx<double> zk = Z[k], zc = cpx<double>{Z[kc].x, -Z[kc].y};
+        const cpx<double> w = p.wl[k];
+        // E, O: transforms of the even and odd samples;  X[k] = E + w O,  X[n-k] = conj(E - w O)
+        const cpx<double> E{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
+        const cpx<double> Bv{0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y)};
+        const cpx<double> O{Bv.y, -Bv.x};                                  // -i Bv
+        const cpx<double> wO{w.x * O.x - w.y * O.y, w.x * O.y + w.y * O.x};
+        const cpx<double> Xk{E.x + wO.x, E.y + wO.y};
+        const cpx<double> Xc{E.x - wO.x, -(E.y - wO.y)};                   // X[n-k]
+        // Y = -i X on the positive bins
+        const cpx<double> Yk{Xk.y, -Xk.x}, Yc{Xc.y, -Xc.x};
+        const cpx<double> Ycc{Yc.x, -Yc.y};                                // conj(Y[n-k])
+        const cpx<double> E2{0.5 * (Yk.x + Ycc.x), 0.5 * (Yk.y + Ycc.y)};
+        const cpx<double> D2{0.5 * (Yk.x - Ycc.x), 0.5 * (Yk.y - Ycc.y)};
+        const cpx<double> O2{w.x * D2.x + w.y * D2.y, w.x * D2.y - w.y * D2.x};   // conj(w) D2
+        // V[k] = E2 + i O2,  V[n-k] = conj(E2) + i conj(O2)
+        Z[k] = cpx<double>{E2.x - O2.y, E2.y + O2.x};
+        if (kc != k) Z[kc] = cpx<double>{E2.x + O2.y, -E2.y + O2.x};
+    }
+}
+
+// envelope[i] = |x[i] + i H(x)[i]|, H(x)[2m] = Re v[m] / n, H(x)[2m+1] = Im v[m] / n
+ECHO_HD void ph_env_abs(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int which) {
+    const cpx<double>* v = env_buf(smem, p, which);
+    double* env = reinterpret_cast<double*>(env_buf(smem, p, which ^ 1));
+    const double* x = p.corr + (size_t)blk * p.L;
+    const double inv_n = 1.0 / (double)p.n;
+    for (int m = tid; m < p.n; m += nt) {
+        const cpx<double> h = v[m];
+        env[2 * m] = hypot(x[2 * m], h.x * inv_n);
+        env[2 * m + 1] = hypot(x[2 * m + 1], h.y * inv_n);
+    }
+}
+
+// -------------------------------------------------------------------------------- smoothing and statistics
+ECHO_HD int reflect_idx(int i, int n) {
+    while (i < 0 || i >= n) i = i < 0 ? -i - 1 : 2 * n - i - 1;
+    return i;
+}
+
+// deterministic block reduction: K partials per thread at scratch[q*nt + tid]; op 0 sum, 1 max, 2 min
+ECHO_HD double red_op(int op, double a, double b) { return op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
+ECHO_HD void red_fold(int tid, int nt, double* scratch, int K, const int* ops) {
+    if (tid >= 64) return;
+    double* fold = scratch + K * nt;
+    for (int q = 0; q < K; ++q) {
+        double a = scratch[q * nt + tid];
+        for (int t = tid + 64; t < nt; t += 64) a = red_op(ops[q], a, scratch[q * nt + t]);
+        fold[q * 64 + tid] = a;
+    }
+}
+ECHO_HD double red_final(const double* scratch, int nt, int K, int q, int op) {
+    const double* fold = scratch + K * nt + q * 64;
+    double a = fold[0];
+    const int lim = nt < 64 ? nt : 64;
+    for (int t = 1; t < lim; ++t) a = red_op(op, a, fold[t]);
+    return a;
+}
+
+// sm = uniform_filter1d(env, size) into the other buffer; round-1 partials into... the env buffer is still being
+// read by neighbours, so the partials are kept by the caller and stored in the next phase
+struct EnvPart1 { double v[7]; };
+ECHO_HD EnvPart1 ph_env_smooth(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int env_in) {
+    const double* env = reinterpret_cast<const double*>(env_buf(smem, p, env_in));
+    double* sm = reinterpret_cast<double*>(env_buf(smem, p, env_in ^ 1));
+    const double* x = p.corr + (size_t)blk * p.L;
+    const int h = p.smooth / 2;
+    EnvPart1 a;
+    a.v[0] = 0.0; a.v[1] = -INFINITY; a.v[2] = INFINITY; a.v[3] = 0.0; a.v[4] = 0.0; a.v[5] = 0.0; a.v[6] = 0.0;
+    for (int i = tid; i < p.L; i += nt) {
+        double s = 0.0;
+        for (int d = -h; d <= h; ++d) s += env[reflect_idx(i + d, p.L)];
+        s = s / (double)p.smooth;
+        sm[i] = s;
+        if (p.env_out) p.env_out[(size_t)blk * p.L + i] = s;
+        const double xv = x[i], ax = fabs(xv);
+        a.v[0] += s; a.v[1] = s > a.v[1] ? s : a.v[1]; a.v[2] = s < a.v[2] ? s : a.v[2];
+        a.v[3] += xv; a.v[4] += xv * xv; a.v[5] = ax > a.v[5] ? ax : a.v[5];
+        if (i < p.min_delay) a.v[6] += s * s;
+    }
+    return a;
+}
+ECHO_HD void ph_env_part1_store(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf, const EnvPart1& a) {
+    double* scratch = reinterpret_cast<double*>(env_buf(smem, p, scratch_buf));
+    for (int q = 0; q < 7; ++q) scratch[q * nt + tid] = a.v[q];
+}
+ECHO_HD void ph_env_part1_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
+    const int ops[7] = {0, 1, 2, 0, 0, 1, 0};
+    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 7, ops);
+}
+ECHO_HD void ph_env_part1_final(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
+    if (tid != 0) return;
+    const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf));
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf ^ 1));
+    EnvMisc* m = env_misc(smem, p);
+    m->sum_sm = red_final(scratch, nt, 7, 0, 0); m->max_sm = red_final(scratch, nt, 7, 1, 1);
+    m->min_sm = red_final(scratch, nt, 7, 2, 2); m->sum_x = red_final(scratch, nt, 7, 3, 0);
+    m->sum_x2 = red_final(scratch, nt, 7, 4, 0); m->amp = red_final(scratch, nt, 7, 5, 1);
+    m->sum_noise = red_final(scratch, nt, 7, 6, 0);
+    m->mean_sm = m->sum_sm / (double)p.L;
+    m->mean_x = m->sum_x / (double)p.L;
+    m->mean_d = p.L > 1 ? (sm[p.L - 1] - sm[0]) / (double)(p.L - 1) : 0.0;
+}
+// round 2: squared deviations (np.std is the two-pass population deviation)
+ECHO_HD void ph_env_part2(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    double* scratch = reinterpret_cast<double*>(env_buf(smem, p, sm_buf ^ 1));
+    const double* x = p.corr + (size_t)blk * p.L;
+    const EnvMisc* m = env_misc(smem, p);
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = tid; i < p.L; i += nt) {
+        const double ds = sm[i] - m->mean_sm, dx = x[i] - m->mean_x;
+        a += ds * ds; b += dx * dx;
+        if (i + 1 < p.L) { const double dd = (sm[i + 1] - sm[i]) - m->mean_d; c += dd * dd; }
+    }
+    scratch[tid] = a; scratch[nt + tid] = b; scratch[2 * nt + tid] = c;
+}
+ECHO_HD void ph_env_part2_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
+    const int ops[3] = {0, 0, 0};
+    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 3, ops);
+}
+ECHO_HD void ph_env_part2_final(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
+    if (tid != 0) return;
+    const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf));
+    EnvMisc* m = env_misc(smem, p);
+    m->ss_sm = red_final(scratch, nt, 3, 0, 0); m->ss_x = red_final(scratch, nt, 3, 1, 0);
+    m->ss_d = red_final(scratch, nt, 3, 2, 0);
+    m->std_sm = sqrt(m->ss_sm / (double)p.L);
+    const double two_std = 2.0 * m->std_sm;
+    m->thr = m->mean_sm + two_std;
+}
+
+// -------------------------------------------------------------------------------- find_peaks
+// state[i]: 0 not a candidate, 1 undecided, 2 kept, 3 removed by the distance rule
+ECHO_HD unsigned char* env_aux(unsigned char* smem, const EnvParams& p, int sm_buf) {
+    return reinterpret_cast<unsigned char*>(env_buf(smem, p, sm_buf ^ 1));
+}
+ECHO_HD void ph_env_candidates(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    unsigned char* state = env_aux(smem, p, sm_buf);
+    double* cmax = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
+    double* cmin = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
+    for (int i = tid; i < p.L; i += nt) state[i] = 0;
+    const int nchunk = (p.L + kEnvChunk - 1) / kEnvChunk;
+    for (int c = tid; c < nchunk; c += nt) {
+        double mx = -INFINITY, mn = INFINITY;
+        const int e = (c + 1) * kEnvChunk < p.L ? (c + 1) * kEnvChunk : p.L;
+        for (int i = c * kEnvChunk; i < e; ++i) { mx = sm[i] > mx ? sm[i] : mx; mn = sm[i] < mn ? sm[i] : mn; }
+        cmax[c] = mx; cmin[c] = mn;
+    }
+}
+// local maxima as scipy's _local_maxima_1d: x[i-1] < x[i], plateau x[i..j] equal, x[j+1] < x[i] -> (i + j) // 2
+ECHO_HD void ph_env_maxima(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    unsigned char* state = env_aux(smem, p, sm_buf);
+    const EnvMisc* m = env_misc(smem, p);
+    for (int i = tid + 1; i < p.L - 1; i += nt) {
+        if (!(sm[i - 1] < sm[i])) continue;
+        int j = i;
+        while (j + 1 < p.L && sm[j + 1] == sm[i]) ++j;
+        if (j + 1 >= p.L || !(sm[j + 1] < sm[i])) continue;
+        const int mid = (i + j) / 2;
+        if (sm[mid] >= m->thr) state[mid] = 1;           // height filter: thr <= peak height
+    }
+}
+ECHO_HD bool env_higher(const double* sm, int j, int i) { return sm[j] > sm[i] || (sm[j] == sm[i] && j > i); }
+// one round of the distance rule: a candidate is removed when a kept candidate of higher priority lies within
+// distance-1 samples, kept when every higher-priority candidate in that range is already removed
+ECHO_HD void ph_env_distance_round(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    unsigned char* state = env_aux(smem, p, sm_buf);
+    EnvMisc* m = env_misc(smem, p);
+    for (int i = tid; i < p.L; i += nt) {
+        if (state[i] != 1) continue;
+        const int lo = i - (p.distance - 1) < 0 ? 0 : i - (p.distance - 1);
+        const int hi = i + (p.distance - 1) >= p.L ? p.L - 1 : i + (p.distance - 1);
+        bool removed = false, wait = false;
+        for (int j = lo; j <= hi; ++j) {
+            const unsigned char sj = state[j];
+            if (sj == 0 || sj == 3 || j == i || !env_higher(sm, j, i)) continue;
+            if (sj == 2) { removed = true; break; }
+            wait = true;
+        }
+        if (removed) state[i] = 3;
+        else if (!wait) state[i] = 2;
+        else env_lds_add(&m->undecided, 1);
+    }
+}
+ECHO_HD void ph_env_collect(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const unsigned char* state = env_aux(smem, p, sm_buf);
+    int* kept = reinterpret_cast<int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
+    EnvMisc* m = env_misc(smem, p);
+    for (int i = tid; i < p.L; i += nt)
+        if (state[i] == 2) {
+            const int slot = env_lds_add(&m->n_kept, 1);
+            if (slot < kEnvMaxKept) kept[slot] = i;
+        }
+}
+// prominence of each kept peak (scipy _peak_prominences, wlen = None) with chunk-wise skipping; peaks below the
+// required prominence (std of the envelope) are dropped; the best surviving peak at or beyond min_delay is chosen
+ECHO_HD double env_side_min(const double* sm, const double* cmax, const double* cmin, int L, int peak, int dir) {
+    const double h = sm[peak];
+    double mn = h;
+    int i = peak + dir;
+    while (i >= 0 && i < L) {
+        const int c = i / kEnvChunk;
+        const int cb = c * kEnvChunk, ce = (c + 1) * kEnvChunk < L ? (c + 1) * kEnvChunk : L;
+        const bool whole = dir < 0 ? (i == ce - 1) : (i == cb);
+        if (whole && cmax[c] <= h) {                     // the whole chunk is at or below the peak: take its minimum
+            mn = cmin[c] < mn ? cmin[c] : mn;
+            i = dir < 0 ? cb - 1 : ce;
+            continue;
+        }
+        if (sm[i] > h) break;
+        mn = sm[i] < mn ? sm[i] : mn;
+        i += dir;
+    }
+    return mn;
+}
+ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    const double* cmax = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
+    const double* cmin = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
+    unsigned char* state = env_aux(smem, p, sm_buf);
+    const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
+    EnvMisc* m = env_misc(smem, p);
+    const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
+    for (int t = tid; t < nk; t += nt) {
+        const int i = kept[t];
+        const double lmin = env_side_min(sm, cmax, cmin, p.L, i, -1);
+        const double rmin = env_side_min(sm, cmax, cmin, p.L, i, +1);
+        const double base = lmin > rmin ? lmin : rmin;
+        const double prom = sm[i] - base;
+        if (!(prom >= m->std_sm)) state[i] = 3;
+        else env_lds_add(&m->n_final, 1);
+    }
+}
+// valid_peaks[np.argmax(corr_envelope[valid_peaks])]: highest surviving peak at index >= min_delay, first on ties
+ECHO_HD void ph_env_select(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    if (tid != 0) return;
+    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    const unsigned char* state = env_aux(smem, p, sm_buf);
+    const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
+    EnvMisc* m = env_misc(smem, p);
+    const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
+    int best = -1;
+    for (int t = 0; t < nk; ++t) {
+        const int i = kept[t];
+        if (state[i] != 2 || i < p.min_delay) continue;
+        if (best < 0 || sm[i] > sm[best] || (sm[i] == sm[best] && i < best)) best = i;
+    }
+    m->best_idx = best;
+    m->best_val = best >= 0 ? sm[best] : 0.0;
+}
+ECHO_HD double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const EnvMisc* m = env_misc(smem, p);
+    EnvRes r;
+    r.peak_idx = m->best_idx; r.n_peaks = m->n_final; r.amplitude = m->amp; r.snr_db = 0.0;
+    if (m->best_idx >= 0) {
+        const double sp = m->best_val * m->best_val;
+        const double npow = (p.min_delay > 0 ? m->sum_noise / (double)p.min_delay : NAN) + 1e-10;
+        r.snr_db = 10.0 * log10(sp / npow);
+    }
+    // calculate_signal_quality(corr, corr_envelope)
+    const double L = (double)p.L;
+    const double signal_power = m->sum_x2 / L;
+    const double noise_est = sqrt(m->ss_x / L);
+    const double snr = 10.0 * log10(signal_power / (noise_est * noise_est + 1e-10));
+    const double std_d = p.L > 1 ? sqrt(m->ss_d / (L - 1.0)) : 0.0;
+    const double smooth = std_d / (m->std_sm + 1e-10);
+    const double dyn = (m->max_sm - m->min_sm) / (m->mean_sm + 1e-10);
+    const double q = clip01(snr / 20.0) * 0.5 + clip01(1.0 - smooth) * 0.3 + clip01(dyn / 2.0) * 0.2;
+    r.quality = clip01(q);
+    p.res_out[blk] = r;
+}
+
+// Barrier-separated sequence of one workgroup.  PHASE runs a statement for every thread (tid in scope); SYNC is a
+// workgroup barrier.  PART1 declares per-thread storage for the smoothing partials: a local on the device, an array
+// indexed by tid on the host.
+#define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
+    do {                                                                                                     \
+        PART1_DECL;                                                                                          \
+        PHASE(ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
+        int cur_ = 0;                                                                                        \
+        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
+            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, false)) SYNC                                  \
+            cur_ ^= 1;                                                                                       \
+        }                                                                                                    \
+        PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
+        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
+            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, true)) SYNC                                   \
+            cur_ ^= 1;                                                                                       \
+        }                                                                                                    \
+        PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
+        cur_ ^= 1;                               /* cur_: envelope */                                        \
+        PHASE(PART1_REF = ph_env_smooth(tid, nt, blk, p, smem, cur_)) SYNC                                   \
+        const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \
+        PHASE(ph_env_part1_store(tid, nt, p, smem, scr_, PART1_REF)) SYNC                                    \
+        PHASE(ph_env_part1_fold(tid, nt, p, smem, scr_)) SYNC                                                \
+        PHASE(ph_env_part1_final(tid, nt, p, smem, scr_)) SYNC                                               \
+        PHASE(ph_env_part2(tid, nt, blk, p, smem, sm_)) SYNC                                                 \
+        PHASE(ph_env_part2_fold(tid, nt, p, smem, scr_)) SYNC                                                \
+        PHASE(ph_env_part2_final(tid, nt, p, smem, scr_)) SYNC                                               \
+        PHASE(ph_env_candidates(tid, nt, p, smem, sm_)) SYNC                                                 \
+        PHASE(ph_env_maxima(tid, nt, p, smem, sm_)) SYNC                                                     \
+        for (int round_ = 0; round_ < (p).L; ++round_) {                                                     \
+            PHASE(if (tid == 0) env_misc(smem, p)->undecided = 0) SYNC                                       \
+            PHASE(ph_env_distance_round(tid, nt, p, smem, sm_)) SYNC                                         \
+            const int left_ = env_misc(smem, p)->undecided;                                                  \
+            SYNC                                                                                             \
+            if (left_ == 0) break;                                                                           \
+        }                                                                                                    \
+        PHASE(ph_env_collect(tid, nt, p, smem, sm_)) SYNC                                                         \
+        PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
+        PHASE(ph_env_select(tid, nt, p, smem, sm_)) SYNC                                                     \
+        PHASE(ph_env_finish(tid, blk, p, smem))                                                              \
+    } while (0)
+
+}  // namespace echo

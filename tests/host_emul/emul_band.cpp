@@ -123,3 +123,60 @@ extern "C" int emul_long(int N, int M, int K, int nb, int min_delay, int detecto
     for (size_t i = 0; i < res.size(); ++i) peak[i] = res[i].peak_idx;
     return 0;
 }
+
+// Generic mixed-radix FFT (dsp_amd/csrc/gfft.h), thread by thread.  in/out: n interleaved (re, im) doubles.
+#include "../../dsp_amd/csrc/gfft.h"
+
+template <class T> static int run_gfft(int n, int inv, const double* in, double* out) {
+    GfftPlan pl;
+    if (!gfft_plan(pl, n)) return -2;
+    std::vector<cpx<T>> roots, wn, a(n), b(n);
+    gfft_tables(pl, roots, wn);
+    for (int i = 0; i < n; ++i) a[i] = cpx<T>{(T)in[2 * i], (T)in[2 * i + 1]};
+    cpx<T>* src = a.data(); cpx<T>* dst = b.data();
+    const int nt = 512;
+    for (int ps = 0; ps < pl.npass; ++ps) {
+        for (int tid = 0; tid < nt; ++tid)
+            gfft_pass<T>(tid, nt, pl, ps, src, dst, roots.data() + pl.root_off[ps], wn.data(), inv != 0);
+        std::swap(src, dst);
+    }
+    for (int i = 0; i < n; ++i) { out[2 * i] = src[i].x; out[2 * i + 1] = src[i].y; }
+    return pl.npass;
+}
+
+extern "C" int emul_gfft(int n, int inv, int use_float, const double* in, double* out) {
+    return use_float ? run_gfft<float>(n, inv, in, out) : run_gfft<double>(n, inv, in, out);
+}
+
+// Envelope branch for the correlation (dsp_amd/csrc/env_phases.h), thread by thread.
+#include "../../dsp_amd/csrc/env_phases.h"
+
+extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* corr, int B, double* env_out,
+                        int* peak, double* snr, double* amp, double* quality, int* npeaks) {
+    EnvParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_env(p, L, nb, min_delay, smooth)) return -2;
+    std::vector<cpx<double>> roots, wn, wl;
+    env_tables(p, roots, wn, wl);
+    p.roots = roots.data(); p.wn = wn.data(); p.wl = wl.data();
+    p.corr = corr; p.env_out = env_out;
+    std::vector<EnvRes> res((size_t)B * nb);
+    p.res_out = res.data();
+    std::vector<unsigned char> smem(p.smem_bytes);
+    unsigned char* s = smem.data();
+    const int nt = kEnvNT;
+    std::vector<EnvPart1> part(nt);
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        ECHO_ENV_SEQUENCE(PHASE, SYNC, (void)0, part[tid], p, s, blk, nt);
+    }
+#undef PHASE
+#undef SYNC
+    for (size_t i = 0; i < res.size(); ++i) {
+        peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude;
+        quality[i] = res[i].quality; npeaks[i] = res[i].n_peaks;
+    }
+    return 0;
+}
