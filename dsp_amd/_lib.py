@@ -14,7 +14,7 @@ MAX_BANDS = 3
 EXPORTS = [
     "echo_create", "echo_destroy", "echo_reserve", "echo_strerror", "echo_version",
     "echo_fir_bank", "echo_bandpass_bank", "echo_spectrum", "echo_mag2db", "echo_correlate",
-    "echo_first_strong_peak", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
+    "echo_first_strong_peak", "echo_envelope_detection", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
     "echo_chain", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
     "echo_set_profiling", "echo_last_kernel_ms",
 ]
@@ -59,6 +59,7 @@ def load():
     lib.echo_mag2db.argtypes = [P, P, C.c_size_t, P]
     lib.echo_correlate.argtypes = [P, P, P, I, P]
     lib.echo_first_strong_peak.argtypes = [P, P, P, P, P, I, P]
+    lib.echo_envelope_detection.argtypes = [P, P, P, P, P, P, P, I, P]
     lib.echo_argmax.argtypes = [P, P, I, I, P]
     lib.echo_confidence_fuse.argtypes = [P, P, P, P, P, I, P]
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]

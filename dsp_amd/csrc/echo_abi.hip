@@ -18,6 +18,12 @@ struct EchoHandle {
     int device = 0;
     bool bodd0 = false;
     BandParams base;                       // sizes, layout and device table pointers
+    bool has_env = false;                  // envelope branch available (even correlation length with small prime factors)
+    EnvParams ebase;
+    cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr;
+    EnvRes* d_env = nullptr;               // envelope-branch results, [frames][nb]
+    double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
+    double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     bool long_path = false;                // frame too long for one workgroup, or the MAD detector: tiled kernels
     LongParams lbase;
     // device constant tables
@@ -25,6 +31,7 @@ struct EchoHandle {
     float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
+    int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
     double* d_fwd = nullptr;               // IIR forward-pass output
     double* d_y = nullptr;                 // IIR result
     float* d_bandf = nullptr;              // float32 band_sig handed from the band kernel to the spectrum kernel
@@ -52,7 +59,9 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
     (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf); (void)hipFree(h->d_band); (void)hipFree(h->d_pos);
-    h->d_bandf = nullptr; h->d_band = h->d_pos = nullptr;
+    (void)hipFree(h->d_env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq);
+    h->d_bandf = nullptr; h->d_band = h->d_pos = nullptr; h->d_env = nullptr; h->d_corr = nullptr; h->d_sq = nullptr;
+    h->cap_full = 0;
     h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
     h->cap_frames = 0;
 }
@@ -73,11 +82,25 @@ int ensure_scratch(EchoHandle* h, int frames) {
                                     (size_t)(h->lbase.L - h->lbase.half) * sizeof(double)) != hipSuccess)) ||
         hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_env), (size_t)frames * c.n_bands * sizeof(EnvRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_vany), (size_t)frames) != hipSuccess) {
         free_scratch(h);
         return ECHO_ERR_NOMEM;
     }
     h->cap_frames = frames;
+    return ECHO_OK;
+}
+
+// scratch of the full chain (raw correlation, signal quality); allocated on first use
+int ensure_full_scratch(EchoHandle* h, int frames) {
+    if (frames <= h->cap_full) return ECHO_OK;
+    (void)hipFree(h->d_corr); (void)hipFree(h->d_sq);
+    h->d_corr = nullptr; h->d_sq = nullptr; h->cap_full = 0;
+    const size_t nbf = (size_t)frames * h->cfg.n_bands;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_corr), nbf * (size_t)h->base.L * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_sq), nbf * sizeof(double)) != hipSuccess)
+        return ECHO_ERR_NOMEM;
+    h->cap_full = frames;
     return ECHO_OK;
 }
 
@@ -180,6 +203,18 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     } else if (rc == ECHO_OK) {
         rc = long_kernels_prepare(h->lbase);
     }
+    std::memset(&h->ebase, 0, sizeof(h->ebase));
+    if (rc == ECHO_OK && !h->long_path &&
+        plan_env(h->ebase, cfg->n_rx + cfg->n_chirp - 1, nb, cfg->min_delay, 5)) {
+        std::vector<cpx<double>> er, ewn, ewl;
+        env_tables(h->ebase, er, ewn, ewl);
+        up(dev_upload(&h->d_eroots, er.data(), er.size()));
+        up(dev_upload(&h->d_ewn, ewn.data(), ewn.size()));
+        up(dev_upload(&h->d_ewl, ewl.data(), ewl.size()));
+        if (rc == ECHO_OK) rc = env_kernel_prepare(h->ebase);
+        h->ebase.roots = h->d_eroots; h->ebase.wn = h->d_ewn; h->ebase.wl = h->d_ewl;
+        h->has_env = rc == ECHO_OK;
+    }
     if (rc != ECHO_OK) { echo_destroy(h); return rc; }
     h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
@@ -193,7 +228,8 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
 void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
-    void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post};
+    void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
+                    h->d_eroots, h->d_ewn, h->d_ewl};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -331,6 +367,28 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
         if (rc) return rc;
         rc = launch_unpack_res(h->d_res, peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb,
                                amplitude ? amplitude + (size_t)f0 * nb : nullptr, n * nb, s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
+int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
+                            double* quality, int32_t* n_peaks, int B, void* stream) {
+    if (!h || !corr || B < 0) return ECHO_ERR_INVALID;
+    if (!h->has_env) return ECHO_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = h->cfg.n_bands;
+    for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+        const int n = std::min(h->max_chunk, B - f0);
+        int rc = ensure_scratch(h, n);
+        if (rc) return rc;
+        EnvParams q = h->ebase;
+        const size_t o = (size_t)f0 * nb;
+        q.corr = corr + o * q.L; q.env_out = envelope ? envelope + o * q.L : nullptr; q.res_out = h->d_env;
+        rc = launch_corr_env(q, n, s);
+        if (rc) return rc;
+        rc = launch_unpack_env(h->d_env, peak_idx ? peak_idx + o : nullptr, snr_db ? snr_db + o : nullptr,
+                               quality ? quality + o : nullptr, n_peaks ? n_peaks + o : nullptr, n * nb, s);
         if (rc) return rc;
     }
     return ECHO_OK;

@@ -5,6 +5,7 @@
 
 #include "band_phases.h"
 #include "long_phases.h"
+#include "env_phases.h"
 
 namespace echo {
 
@@ -47,6 +48,10 @@ int long_kernels_prepare(const LongParams& p);
 int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <= 65535 per launch
 int launch_long_corr(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
+int env_kernel_prepare(const EnvParams& p);
+int launch_corr_env(const EnvParams& p, int B, hipStream_t s);
+int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,
+                      hipStream_t s);
 int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, BandRes* res, int n, hipStream_t s);
 int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s);
 int launch_fuse(const FuseParams& p, hipStream_t s);

@@ -120,6 +120,16 @@ __global__ void unpack_res_kernel(const BandRes* res, int32_t* peak, double* snr
     if (amp) amp[i] = r.amplitude;
 }
 
+__global__ void unpack_env_kernel(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const EnvRes r = res[i];
+    if (peak) peak[i] = r.peak_idx;
+    if (snr) snr[i] = r.snr_db;
+    if (quality) quality[i] = r.quality;
+    if (npeaks) npeaks[i] = r.n_peaks;
+}
+
 // gpu_argmax: first index of the row maximum (np.argmax), one wavefront per row
 __global__ __launch_bounds__(256) void argmax_kernel(const double* x, int32_t* out, int rows, int n) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -160,6 +170,12 @@ int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, B
 int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(unpack_res_kernel, dim3((n + 255) / 256), dim3(256), 0, s, res, peak, snr, amp, n);
+    return ok();
+}
+int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,
+                      hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(unpack_env_kernel, dim3((n + 255) / 256), dim3(256), 0, s, res, peak, snr, quality, npeaks, n);
     return ok();
 }
 int launch_argmax(const double* x, int32_t* out, int rows, int n, hipStream_t s) {

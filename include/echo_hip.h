@@ -123,6 +123,16 @@ int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, v
 int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db,
                            double* amplitude, int B, void* stream);
 
+/* gpu_envelope_detection(corr, 'hilbert', smooth_window=5) and the envelope-path peak choice of _process_band_gpu
+ * (airSonar_optimized.py:431-475, :642-654; calculate_signal_quality :477-490; scipy.signal.hilbert,
+ * uniform_filter1d, find_peaks(height = mean + 2 std, distance = L // 50, prominence = std)).
+ * corr[B][nb][L] is the raw correlation and is not modified.  Outputs, each optional (NULL to skip):
+ * envelope[B][nb][L] smoothed envelope; peak_idx[B][nb] = valid_peaks[argmax(envelope[valid_peaks])] as an index into
+ * corr, or -1 when no peak lies at or beyond min_delay (the caller then falls back to first_strong_peak, :657);
+ * snr_db[B][nb] (:652-654); quality[B][nb] = corr_quality; n_peaks[B][nb] = len(corr_peaks). */
+int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
+                            double* quality, int32_t* n_peaks, int B, void* stream);
+
 /* gpu_argmax (airSonar_optimized.py:359-368): first index of the maximum of each row of x[rows][n]. */
 int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream);
 

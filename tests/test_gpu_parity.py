@@ -327,3 +327,32 @@ def test_chain_one_million_frames_periodic_input(eng_default):
     z = r["fused_dist"][0::S][:2000].astype(np.float64)
     want = np.array([kf.update(v) for v in z])
     np.testing.assert_allclose(r["kalman"][0::S][:2000], want, rtol=1e-5)
+
+
+def test_envelope_detection_against_oracle(gold_default, eng_default):
+    """Envelope branch on the correlation (Hilbert envelope, uniform_filter1d(5), find_peaks with height, distance
+    and prominence, envelope-path peak and SNR, corr_quality): golden envelopes, and SciPy through the oracle on the
+    correlations of 256 synthetic frames -- peak choice and peak count exact."""
+    g = gold_default
+    cfg = eng_default.cfg
+    r = eng_default.envelope_detection(g["stage_corr"])
+    env = r["envelope"].cpu().numpy()
+    ref = g["stage_corr_envelope"].astype(np.float64)
+    assert np.abs(env - ref).max() <= 2e-7 * np.abs(ref).max()          # golden envelope is stored as float32
+    rx = synth_frames(256, cfg, eng_default.tables.tx_pcm)
+    corr = eng_default.correlate(eng_default.bandpass_bank(rx))
+    r = eng_default.envelope_detection(corr)
+    c = corr.cpu().numpy()
+    env = r["envelope"].cpu().numpy(); peak = r["peak_idx"].cpu().numpy(); npk = r["n_peaks"].cpu().numpy()
+    snr = r["snr_db"].cpu().numpy(); q = r["quality"].cpu().numpy()
+    for f in range(c.shape[0]):
+        for b in range(c.shape[1]):
+            e, pk, qual = O.gpu_envelope_detection(c[f, b], 5)
+            assert np.abs(env[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
+            vp = pk[pk >= cfg.min_delay]
+            want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
+            assert (want, len(pk)) == (peak[f, b], npk[f, b]), (f, b)
+            assert abs(qual - q[f, b]) <= 1e-9
+            if want >= 0:
+                s = 10 * np.log10(e[want] ** 2 / (np.mean(e[:cfg.min_delay] ** 2) + 1e-10))
+                assert abs(s - snr[f, b]) <= 1e-9 * max(1.0, abs(s))
