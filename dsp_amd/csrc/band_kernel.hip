@@ -73,6 +73,55 @@ __global__ __launch_bounds__(kNT, 4) void spec_kernel(BandParams p) {
     STAMP(16);
 }
 
+// The 8192-point cyclic convolution of the Bluestein transform, in place in LDS (entered after a barrier, leaves
+// after one): forward passes, register-resident middle with the chirp-filter product, inverse passes.
+__device__ __forceinline__ void bluestein_round(int tid, const BandParams& p, unsigned char* smem) {
+    Tw3 tw = fft_tw_load(tid, 1024, p);
+    ph_fft_r8<false>(tid, 1024, p, smem, tw);
+    tw = fft_tw_load(tid, 128, p);
+    __syncthreads();
+    ph_fft_r8<false>(tid, 128, p, smem, tw);
+    tw = fft_tw_load(tid, 16, p);
+    __syncthreads();
+    ph_fft_r8<false>(tid, 16, p, smem, tw);
+    __syncthreads();
+    {
+        const Bh8 bh = fft_bh_load(tid, p);
+        ph_fft_mid(tid, p, smem, bh);
+    }
+    tw = fft_tw_load(tid, 16, p);
+    __syncthreads();
+    ph_fft_r8<true>(tid, 16, p, smem, tw);
+    tw = fft_tw_load(tid, 128, p);
+    __syncthreads();
+    ph_fft_r8<true>(tid, 128, p, smem, tw);
+    tw = fft_tw_load(tid, 1024, p);
+    __syncthreads();
+    ph_fft_r8<true>(tid, 1024, p, smem, tw);
+    __syncthreads();
+}
+
+// Spectrum plus the envelope branch of the band signal (hilb_phases.h): dB spectrum and signal_quality.
+__global__ __launch_bounds__(kNT, 4) void spec_hilbert_kernel(BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    ph_spec_load(tid, kNT, blk, p, smem);
+    __syncthreads();
+    bluestein_round(tid, p, smem);
+    ph_hilb_mid(tid, kNT, blk, p, smem);
+    __syncthreads();
+    bluestein_round(tid, p, smem);
+    ph_hilb_env(tid, kNT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_smooth(tid, kNT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_stats1(tid, kNT, p, smem);
+    __syncthreads();
+    ph_hilb_dev(tid, kNT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_finish(tid, kNT, blk, p, smem);
+}
+
 #ifdef ECHO_DIAG_STAMPS
 extern "C" int echo_diag_read_stamps(unsigned long long* host, int n) {
     if (n > kStampBlocks * kStampSlots) n = kStampBlocks * kStampSlots;
@@ -87,12 +136,22 @@ int band_kernel_prepare(int smem_bytes, int spec_smem_bytes) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, spec_smem_bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_hilbert_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, spec_smem_bytes);
     return e == hipSuccess ? 0 : -4;
 }
 
 int launch_spec(const BandParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(spec_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_spec_hilbert(const BandParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!p.specf_in || !p.sq_out || !p.spec_out || !p.uk || !hilb_fits(p.N, p.n2)) return -1;
+    hipLaunchKernelGGL(spec_hilbert_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -89,6 +89,8 @@ struct BandParams {
     const float* specf_in;           // spectrum kernel input, float32 [B][nb][N] (or null)
     const double* specd_in;          // spectrum kernel input, float64 [B][nb][N] (or null)
     BandRes* res_out;                // [B][nb]
+    const float2* uk;                // [n2+1] exp(-2*pi*i*k/N) (envelope branch of the spectrum kernel)
+    double* sq_out;                  // [B][nb] signal_quality (envelope branch; null = spectrum only)
     int write_corr_mutated;          // MODE_CORR: write the zeroed blind zone back
 };
 

@@ -24,6 +24,8 @@ struct EchoHandle {
     EnvRes* d_env = nullptr;               // envelope-branch results, [frames][nb]
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
+    float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
+    float2* d_uk = nullptr;
     bool long_path = false;                // frame too long for one workgroup, or the MAD detector: tiled kernels
     LongParams lbase;
     // device constant tables
@@ -59,7 +61,8 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
     (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf); (void)hipFree(h->d_band); (void)hipFree(h->d_pos);
-    (void)hipFree(h->d_env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq);
+    (void)hipFree(h->d_env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
+    h->d_spec = nullptr;
     h->d_bandf = nullptr; h->d_band = h->d_pos = nullptr; h->d_env = nullptr; h->d_corr = nullptr; h->d_sq = nullptr;
     h->cap_full = 0;
     h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
@@ -94,11 +97,12 @@ int ensure_scratch(EchoHandle* h, int frames) {
 // scratch of the full chain (raw correlation, signal quality); allocated on first use
 int ensure_full_scratch(EchoHandle* h, int frames) {
     if (frames <= h->cap_full) return ECHO_OK;
-    (void)hipFree(h->d_corr); (void)hipFree(h->d_sq);
-    h->d_corr = nullptr; h->d_sq = nullptr; h->cap_full = 0;
+    (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
+    h->d_corr = nullptr; h->d_sq = nullptr; h->d_spec = nullptr; h->cap_full = 0;
     const size_t nbf = (size_t)frames * h->cfg.n_bands;
     if (hipMalloc(reinterpret_cast<void**>(&h->d_corr), nbf * (size_t)h->base.L * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_sq), nbf * sizeof(double)) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&h->d_sq), nbf * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_spec), nbf * (size_t)h->base.nbins * sizeof(float)) != hipSuccess)
         return ECHO_ERR_NOMEM;
     h->cap_full = frames;
     return ECHO_OK;
@@ -124,6 +128,7 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
     p.B = B; p.nb = h->cfg.n_bands; p.fs = h->cfg.fs; p.range_offset = h->cfg.range_offset;
     p.confidence = h->cfg.confidence; p.fusion = h->cfg.fusion; p.sound_speed = h->cfg.sound_speed;
     for (int j = 0; j < 3; ++j) p.fw[j] = h->cfg.freq_weights[j];
+    p.env = nullptr; p.sq = nullptr; p.quality_out = nullptr;
     return p;
 }
 
@@ -199,6 +204,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         up(dev_upload(&h->d_bhat, t.bhat.data(), t.bhat.size()));
         up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
         up(dev_upload(&h->d_post, t.post.data(), t.post.size()));
+        up(dev_upload(&h->d_uk, t.uk.data(), t.uk.size()));
         if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
     } else if (rc == ECHO_OK) {
         rc = long_kernels_prepare(h->lbase);
@@ -218,6 +224,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (rc != ECHO_OK) { echo_destroy(h); return rc; }
     h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
+    h->base.uk = h->d_uk;
     h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
@@ -229,7 +236,7 @@ void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
-                    h->d_eroots, h->d_ewn, h->d_ewl};
+                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -426,9 +433,11 @@ int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const
     return launch_kalman(k, static_cast<hipStream_t>(stream));
 }
 
-int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
-               uint8_t* kalman_init, int B, int n_streams, void* stream) {
+static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
+                      double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
+                      double* quality) {
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
+    if (full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) return ECHO_ERR_UNSUPPORTED;
     const bool kal = kalman_x || kalman_p || kalman_init;
     if (kal && (!kalman_x || !kalman_p || !kalman_init || n_streams < 1 || B % n_streams != 0)) return ECHO_ERR_INVALID;
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
@@ -446,6 +455,7 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         const int n = std::min(chunk, B - f0);
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
+        if (full) { rc = ensure_full_scratch(h, n); if (rc) return rc; }
         const bool prof = h->prof && f0 == 0 && h->prof_used < h->prof_slots;
         hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
@@ -464,6 +474,13 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
             q.det_io = h->d_pos; q.det_stride = q.L - q.half; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
             rc = launch_long_detect(q, n, s);
             if (rc) return rc;
+        } else if (full) {
+            // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
+            BandParams p = h->base;
+            p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 0;
+            p.d_in = h->d_y; p.res_out = h->d_res; p.corr_io = h->d_corr; p.bandf_out = h->d_bandf;
+            rc = launch_band(p, n, s);
+            if (rc) return rc;
         } else {
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
@@ -473,14 +490,26 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
             if (rc) return rc;
         }
         if (prof) (void)hipEventRecord(ev[2], s);
-        if (spec_db) {
+        if (full) {
+            BandParams q = h->base;
+            q.spec_db = 1; q.specf_in = h->d_bandf; q.sq_out = h->d_sq;
+            q.spec_out = spec_db ? spec_db + (size_t)f0 * nb * q.nbins : h->d_spec;
+            rc = launch_spec_hilbert(q, n, s);
+            if (rc) return rc;
+            EnvParams e = h->ebase;
+            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = h->d_env;
+            rc = launch_corr_env(e, n, s);
+            if (rc) return rc;
+        } else if (spec_db) {
             BandParams q = h->base;
             q.spec_db = 1; q.specf_in = h->d_bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
             rc = launch_spec(q, n, s);
             if (rc) return rc;
         }
         if (prof) (void)hipEventRecord(ev[3], s);
-        rc = launch_fuse(fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n), s);
+        FuseParams fp = fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n);
+        if (full) { fp.env = h->d_env; fp.sq = h->d_sq; fp.quality_out = quality ? quality + (size_t)f0 * nb * 2 : nullptr; }
+        rc = launch_fuse(fp, s);
         if (rc) return rc;
         if (kal) {
             KalmanParams k;
@@ -493,6 +522,16 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
         if (prof) { (void)hipEventRecord(ev[4], s); ++h->prof_used; }
     }
     return ECHO_OK;
+}
+
+int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
+               uint8_t* kalman_init, int B, int n_streams, void* stream) {
+    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, false, nullptr);
+}
+
+int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality, double* kalman_x,
+                    double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
+    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
 }
 
 struct EchoGraph {

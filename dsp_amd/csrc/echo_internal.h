@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "band_phases.h"
+#include "hilb_phases.h"
 #include "long_phases.h"
 #include "env_phases.h"
 
@@ -28,6 +29,10 @@ struct FuseParams {
     int B, nb, fs, range_offset, confidence, fusion;
     double sound_speed;
     double fw[3];
+    // full chain (envelope branch): per (frame, band) envelope results and signal quality; null = named chain
+    const EnvRes* env;
+    const double* sq;
+    double* quality_out;  // optional [B][nb][2]: signal_quality, corr_quality
 };
 
 struct KalmanParams {
@@ -44,6 +49,7 @@ int launch_iir_quad(const IirParams& p, int ncoef, hipStream_t s);             /
 int launch_band(const BandParams& p, int B, hipStream_t s);
 int band_kernel_prepare(int smem_bytes, int spec_smem_bytes);
 int launch_spec(const BandParams& p, int B, hipStream_t s);
+int launch_spec_hilbert(const BandParams& p, int B, hipStream_t s);   // spectrum + signal_quality of the band signal
 int long_kernels_prepare(const LongParams& p);
 int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <= 65535 per launch
 int launch_long_corr(const LongParams& p, int B, hipStream_t s);

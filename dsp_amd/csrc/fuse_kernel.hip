@@ -22,7 +22,21 @@ __global__ void fuse_kernel(FuseParams p) {
     r.valid_mask = 0;
     for (int j = 0; j < ECHO_MAX_BANDS; ++j) { r.dist[j] = 0.f; r.conf[j] = 0.f; r.snr_db[j] = 0.f; r.peak_idx[j] = -1; }
     for (int j = 0; j < p.nb; ++j) {
-        const BandRes br = p.res[(size_t)i * p.nb + j];
+        BandRes br = p.res[(size_t)i * p.nb + j];
+        double qfactor = 0.0;
+        if (p.env) {
+            // _process_band_gpu (airSonar_optimized.py:647-671): the envelope peak when one lies at or beyond
+            // min_delay (index into corr, SNR from the envelope, amplitude of the unmodified corr), otherwise the
+            // first_strong_peak result; confidence scaled by the mean of the two quality scores
+            const EnvRes e = p.env[(size_t)i * p.nb + j];
+            const double sq = p.sq[(size_t)i * p.nb + j];
+            if (e.peak_idx >= 0) { br.peak_idx = e.peak_idx; br.snr_db = e.snr_db; br.amplitude = e.amplitude; }
+            qfactor = (sq + e.quality) / 2.0;
+            if (p.quality_out) {
+                p.quality_out[((size_t)i * p.nb + j) * 2] = sq;
+                p.quality_out[((size_t)i * p.nb + j) * 2 + 1] = e.quality;
+            }
+        }
         r.peak_idx[j] = br.peak_idx;
         if (br.peak_idx < 0) continue;
         const double delay = (double)(br.peak_idx - p.range_offset);
@@ -35,6 +49,7 @@ __global__ void fuse_kernel(FuseParams p) {
         } else if (p.confidence == ECHO_CONF_RAW) {
             conf = fmin((br.snr_db / 10.0) * 0.5 + (br.amplitude / 0.1) * 0.3 + p.fw[j] * 0.2, 1.0);
         }
+        if (p.env) conf = conf * (0.5 + 0.5 * qfactor);
         r.dist[j] = (float)dist; r.conf[j] = (float)conf; r.snr_db[j] = (float)br.snr_db;
         r.valid_mask |= 1u << j;
         d[nvalid] = dist; c[nvalid] = conf; ++nvalid;

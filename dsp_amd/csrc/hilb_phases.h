@@ -1,0 +1,181 @@
+// Envelope branch for the band signal: signal_quality of gpu_envelope_detection(band_sig, 'hilbert', smooth_window=3)
+// (airSonar_optimized.py:636, :431-475, :477-490).  Only the quality score of this call is used by the reference
+// (its peaks are discarded), and the score enters the confidence at 1e-4, so the work is float32 and rides on the
+// spectrum kernel: the rfft it already computes gives X; V (the packed spectrum of the Hilbert transform, see
+// env_phases.h) goes through the same Bluestein machinery once more (inverse transform as conj(DFT(conj V))).
+// Phases of (tid, nt); plain C++ apart from the wavefront reduction.
+#pragma once
+#include "band_phases.h"
+
+namespace echo {
+
+struct HilbMisc {
+    double sum_sm, max_sm, min_sm, sum_x, sum_x2;
+    double ss_sm, ss_x, ss_d;
+    double mean_sm, mean_x, mean_d;
+};
+
+// byte offsets inside the 64-KB FFT buffer, beyond the 2144 elements the second transform's output occupies
+constexpr int kHilbOffEnv = 20480;                 // float env[N]
+constexpr int kHilbOffSm = 38912;                  // float sm[N]
+constexpr int kHilbOffRed = 57344;                 // double red[5][slots] (slots = wavefronts on the device)
+                                                   // followed by HilbMisc
+constexpr int kHilbMaxN = (kHilbOffSm - kHilbOffEnv) / 4;
+
+// frame sizes the layout above holds: the second transform's output (n2 elements, whole 32-element swizzle blocks)
+// must end before env[], and env[] / sm[] hold N floats each
+ECHO_HD bool hilb_fits(int N, int n2) { return ((n2 + 31) & ~31) * 8 <= kHilbOffEnv && N <= kHilbMaxN && N * 4 <= kHilbOffRed - kHilbOffSm; }
+
+ECHO_HD int hilb_slots(int nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return nt / 64;
+#else
+    return nt;
+#endif
+}
+ECHO_HD HilbMisc* hilb_misc(unsigned char* smem, int nt) {
+    return reinterpret_cast<HilbMisc*>(smem + kHilbOffRed + 5 * 8 * hilb_slots(nt));
+}
+
+// X from the first transform (dB spectrum out), V in, as the next Bluestein input a2[k] = conj(V[k]) w[k]
+ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    float2* f = lds_c(smem, p.off_fft);
+    const int n2 = p.n2;
+    for (int k = tid; k <= n2 / 2; k += nt) {
+        const float2 wk = p.bw[k];
+        const float2 zk = cmul(f[fa(k)], wk);
+        if (k == 0) {
+            float m0 = fabsf(zk.x + zk.y), m1 = fabsf(zk.x - zk.y);
+            if (p.spec_db) { m0 = 20.0f * log10f(fmaxf(m0, 1e-12f)); m1 = 20.0f * log10f(fmaxf(m1, 1e-12f)); }
+            p.spec_out[(size_t)blk * p.nbins] = m0;
+            p.spec_out[(size_t)blk * p.nbins + n2] = m1;
+            f[fa(0)] = mk2(0.f, 0.f);
+            continue;
+        }
+        const int kc = n2 - k;
+        const float2 wc = p.bw[kc];
+        float2 zc = cmul(f[fa(kc)], wc); zc.y = -zc.y;                      // conj(Z[n2-k])
+        const float2 u = p.uk[k];                                            // exp(-2*pi*i*k/N)
+        const float2 E = mk2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+        const float2 Bv = mk2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
+        const float2 O = mk2(Bv.y, -Bv.x);
+        const float2 uO = cmul(u, O);
+        const float2 Xk = mk2(E.x + uO.x, E.y + uO.y);
+        const float2 Xc = mk2(E.x - uO.x, -(E.y - uO.y));
+        float mk_ = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mc_ = sqrtf(Xc.x * Xc.x + Xc.y * Xc.y);
+        if (p.spec_db) { mk_ = 20.0f * log10f(fmaxf(mk_, 1e-12f)); mc_ = 20.0f * log10f(fmaxf(mc_, 1e-12f)); }
+        p.spec_out[(size_t)blk * p.nbins + k] = mk_;
+        if (kc != k) p.spec_out[(size_t)blk * p.nbins + kc] = mc_;
+        const float2 Yk = mk2(Xk.y, -Xk.x), Ycc = mk2(Xc.y, Xc.x);           // Y = -i X; conj(Y[n2-k])
+        const float2 E2 = mk2(0.5f * (Yk.x + Ycc.x), 0.5f * (Yk.y + Ycc.y));
+        const float2 D2 = mk2(0.5f * (Yk.x - Ycc.x), 0.5f * (Yk.y - Ycc.y));
+        const float2 O2 = cmulc(D2, u);                                      // conj(u) D2
+        const float2 Vk = mk2(E2.x - O2.y, E2.y + O2.x), Vc = mk2(E2.x + O2.y, -E2.y + O2.x);
+        f[fa(k)] = cmul(mk2(Vk.x, -Vk.y), wk);
+        if (kc != k) f[fa(kc)] = cmul(mk2(Vc.x, -Vc.y), wc);
+    }
+    for (int i = n2 + tid; i < kFftM; i += nt) f[fa(i)] = mk2(0.f, 0.f);
+}
+
+// envelope = |x + i H(x)|: D = DFT(conj V) = c2 w; H(x)[2m] = Re D / n2, H(x)[2m+1] = -Im D / n2
+ECHO_HD void ph_hilb_env(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    const float2* f = lds_c(smem, p.off_fft);
+    float* env = reinterpret_cast<float*>(smem + p.off_fft + kHilbOffEnv);
+    const float2* x = reinterpret_cast<const float2*>(p.specf_in + (size_t)blk * p.N);
+    const float inv = 1.0f / (float)p.n2;
+    for (int m = tid; m < p.n2; m += nt) {
+        const float2 d = cmul(f[fa(m)], p.bw[m]);
+        const float2 xv = x[m];
+        env[2 * m] = hypotf(xv.x, d.x * inv);
+        env[2 * m + 1] = hypotf(xv.y, -d.y * inv);
+    }
+}
+
+// per-wavefront partials on the device, per-thread partials on the host; op 0 sum, 1 max, 2 min
+ECHO_HD void hilb_red_store(int tid, int nt, unsigned char* smem, double (&v)[5], int k, const int* ops) {
+    double* red = reinterpret_cast<double*>(smem + kHilbOffRed);
+    const int slots = hilb_slots(nt);
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int q = 0; q < k; ++q)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b = __shfl_xor(v[q], o);
+            v[q] = ops[q] == 0 ? v[q] + b : (ops[q] == 1 ? (b > v[q] ? b : v[q]) : (b < v[q] ? b : v[q]));
+        }
+    if ((tid & 63) == 0)
+        for (int q = 0; q < k; ++q) red[q * slots + tid / 64] = v[q];
+#else
+    for (int q = 0; q < k; ++q) red[q * slots + tid] = v[q];
+#endif
+}
+ECHO_HD double hilb_red_total(int nt, const unsigned char* smem, int q, int op) {
+    const double* red = reinterpret_cast<const double*>(smem + kHilbOffRed);
+    const int slots = hilb_slots(nt);
+    double a = red[q * slots];
+    for (int t = 1; t < slots; ++t) {
+        const double b = red[q * slots + t];
+        a = op == 0 ? a + b : (op == 1 ? (b > a ? b : a) : (b < a ? b : a));
+    }
+    return a;
+}
+
+ECHO_HD int hilb_reflect(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - i - 1 : i); }
+
+// uniform_filter1d(env, 3, mode='reflect') and the first-round sums
+ECHO_HD void ph_hilb_smooth(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    const float* env = reinterpret_cast<const float*>(smem + p.off_fft + kHilbOffEnv);
+    float* sm = reinterpret_cast<float*>(smem + p.off_fft + kHilbOffSm);
+    const float* x = p.specf_in + (size_t)blk * p.N;
+    double v[5] = {0.0, -INFINITY, INFINITY, 0.0, 0.0};
+    for (int i = tid; i < p.N; i += nt) {
+        const float s = (env[hilb_reflect(i - 1, p.N)] + env[i] + env[hilb_reflect(i + 1, p.N)]) / 3.0f;
+        sm[i] = s;
+        const double sd = (double)s, xd = (double)x[i];
+        v[0] += sd; v[1] = sd > v[1] ? sd : v[1]; v[2] = sd < v[2] ? sd : v[2];
+        v[3] += xd; v[4] += xd * xd;
+    }
+    const int ops[5] = {0, 1, 2, 0, 0};
+    hilb_red_store(tid, nt, smem, v, 5, ops);
+}
+ECHO_HD void ph_hilb_stats1(int tid, int nt, const BandParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    HilbMisc* m = hilb_misc(smem, nt);
+    const float* sm = reinterpret_cast<const float*>(smem + p.off_fft + kHilbOffSm);
+    m->sum_sm = hilb_red_total(nt, smem, 0, 0); m->max_sm = hilb_red_total(nt, smem, 1, 1);
+    m->min_sm = hilb_red_total(nt, smem, 2, 2); m->sum_x = hilb_red_total(nt, smem, 3, 0);
+    m->sum_x2 = hilb_red_total(nt, smem, 4, 0);
+    m->mean_sm = m->sum_sm / (double)p.N; m->mean_x = m->sum_x / (double)p.N;
+    m->mean_d = p.N > 1 ? ((double)sm[p.N - 1] - (double)sm[0]) / (double)(p.N - 1) : 0.0;
+}
+ECHO_HD void ph_hilb_dev(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    const float* sm = reinterpret_cast<const float*>(smem + p.off_fft + kHilbOffSm);
+    const float* x = p.specf_in + (size_t)blk * p.N;
+    const HilbMisc* m = hilb_misc(smem, nt);
+    const double mean_sm = m->mean_sm, mean_x = m->mean_x, mean_d = m->mean_d;
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < p.N; i += nt) {
+        const double a = (double)sm[i] - mean_sm, b = (double)x[i] - mean_x;
+        v[0] += a * a; v[1] += b * b;
+        if (i + 1 < p.N) { const double d = ((double)sm[i + 1] - (double)sm[i]) - mean_d; v[2] += d * d; }
+    }
+    const int ops[5] = {0, 0, 0, 0, 0};
+    hilb_red_store(tid, nt, smem, v, 3, ops);
+}
+ECHO_HD double hilb_clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+// calculate_signal_quality(band_sig, envelope)
+ECHO_HD void ph_hilb_finish(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const HilbMisc* m = hilb_misc(smem, nt);
+    const double N = (double)p.N;
+    const double ss_sm = hilb_red_total(nt, smem, 0, 0), ss_x = hilb_red_total(nt, smem, 1, 0);
+    const double ss_d = hilb_red_total(nt, smem, 2, 0);
+    const double std_sm = sqrt(ss_sm / N), noise = sqrt(ss_x / N);
+    const double snr = 10.0 * log10((m->sum_x2 / N) / (noise * noise + 1e-10));
+    const double std_d = p.N > 1 ? sqrt(ss_d / (N - 1.0)) : 0.0;
+    const double smooth = std_d / (std_sm + 1e-10);
+    const double dyn = (m->max_sm - m->min_sm) / (m->mean_sm + 1e-10);
+    const double q = hilb_clip01(snr / 20.0) * 0.5 + hilb_clip01(1.0 - smooth) * 0.3 + hilb_clip01(dyn / 2.0) * 0.2;
+    p.sq_out[blk] = hilb_clip01(q);
+}
+
+}  // namespace echo

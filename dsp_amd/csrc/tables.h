@@ -13,7 +13,7 @@ namespace echo {
 struct HostTables {
     std::vector<double> taps_rev;   // [nb][kgroups*kR]
     std::vector<double> chirp;      // [nb][mgroups*kR]
-    std::vector<float2> bw, bhat, tw, post;
+    std::vector<float2> bw, bhat, tw, post, uk;
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -133,6 +133,11 @@ inline void build_tables(HostTables& t, const BandParams& p, const double* taps,
             }
     // post table: A[k] = w[ka] (1 - i u_k)/2, B[k] = conj(w[kb]) (1 + i u_k)/2, u_k = exp(-2*pi*i*k/N),
     // ka = k mod n2, kb = (n2 - k) mod n2
+    t.uk.resize((size_t)n2 + 1);
+    for (int k = 0; k <= n2; ++k) {
+        const double ang = -2.0 * pi * (double)k / (double)N;
+        t.uk[k] = mk(std::cos(ang), std::sin(ang));
+    }
     t.post.resize((size_t)2 * (n2 + 1));
     for (int k = 0; k <= n2; ++k) {
         const double ang = -2.0 * pi * (double)k / (double)N;

@@ -165,8 +165,11 @@ class EchoEngine:
         return out
 
     def chain(self, rx, n_streams: Optional[int] = None, kalman: Optional["BatchedKalman"] = None,
-              want_spectra: bool = True, out=None, spec_out=None):
+              want_spectra: bool = True, out=None, spec_out=None, mode: str = "named", quality_out=None):
         """The fused per-frame chain. rx [B,N] f32 (time-major over n_streams streams).
+        mode="named": first_strong_peak path; mode="full": _process_band_gpu with its envelope branch
+        (airSonar_optimized.py:629-676); quality_out (full mode): f64 [B,nb,2] tensor receiving
+        (signal_quality, corr_quality).
         Returns (records uint8 [B,64], spec_db f32 [B,nb,bins] or None)."""
         rx = self._dev(rx, torch.float32)
         assert rx.dim() == 2 and rx.shape[1] == self.cfg.n_rx, "rx must be [B, n_rx]"
@@ -181,8 +184,13 @@ class EchoEngine:
         if kalman is not None:
             assert kalman.S == S
             kx, kp, ki = kalman.x, kalman.p, kalman.init
-        _lib.check(self.lib.echo_chain(self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(kx), _ptr(kp), _ptr(ki),
-                                       B, S, self._stream()), "echo_chain")
+        if mode == "full":
+            _lib.check(self.lib.echo_chain_full(self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(quality_out), _ptr(kx),
+                                                _ptr(kp), _ptr(ki), B, S, self._stream()), "echo_chain_full")
+        else:
+            assert mode == "named"
+            _lib.check(self.lib.echo_chain(self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(kx), _ptr(kp), _ptr(ki),
+                                           B, S, self._stream()), "echo_chain")
         return out, spec
 
     def capture_chain(self, rx: torch.Tensor, kalman: "BatchedKalman", want_spectra: bool = False) -> "ChainGraph":

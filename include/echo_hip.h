@@ -155,6 +155,16 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
                double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                int B, int n_streams, void* stream);
 
+/* The whole of SonarWorker._process_band_gpu per band (airSonar_optimized.py:629-676), envelope branch included:
+ * signal_quality from the Hilbert envelope of band_sig (:636), gpu_envelope_detection of the correlation (:642),
+ * the envelope peak at or beyond min_delay as peak_idx (an index into corr) with the envelope SNR (:647-654), else
+ * the first_strong_peak result (:657); amplitude = max|corr| of whichever corr that path leaves (:666); confidence
+ * scaled by 0.5 + 0.5 * (signal_quality + corr_quality) / 2 (:670-671); then fusion and Kalman as echo_chain.
+ * quality (optional) receives [B][nb][2] = signal_quality, corr_quality.  Other arguments as echo_chain. */
+int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality,
+                    double* kalman_x, double* kalman_p, uint8_t* kalman_init,
+                    int B, int n_streams, void* stream);
+
 /* Streaming mode (realtime_sonar.py:300-350: one frame per stream per tick, Kalman state carried between ticks):
  * echo_graph_create records one echo_chain call with exactly these arguments into a HIP graph (stream capture on
  * `stream`, which must not be the null stream; nothing executes during the capture).  echo_graph_launch replays it:

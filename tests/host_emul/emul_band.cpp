@@ -180,3 +180,48 @@ extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* 
     }
     return 0;
 }
+
+// Spectrum kernel with the band-signal envelope branch (dsp_amd/csrc/hilb_phases.h): dB spectrum + signal_quality.
+#include "../../dsp_amd/csrc/hilb_phases.h"
+
+extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps, const double* chirps,
+                                 const float* bandf, int B, float* spec_out, double* sq_out) {
+    BandParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_band(p, N, M, K, nb, 0, 0, 0, 6.0) || !hilb_fits(p.N, p.n2)) return -2;
+    HostTables t;
+    build_tables(t, p, taps, chirps);
+    p.bw = t.bw.data(); p.bhat = t.bhat.data(); p.tw = t.tw.data(); p.post = t.post.data(); p.uk = t.uk.data();
+    p.spec_db = 1; p.specf_in = bandf; p.spec_out = spec_out; p.sq_out = sq_out;
+    const int nt = kNT;
+    std::vector<unsigned char> smem(p.spec_smem_bytes + 5 * 8 * nt + 1024);
+    unsigned char* s = smem.data();
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+    auto round = [&]() {
+        std::vector<Tw3> tw1024(nt), tw128(nt), tw16(nt);
+        std::vector<Bh8> bh(nt);
+        PHASE(tw1024[tid] = fft_tw_load(tid, 1024, p); tw128[tid] = fft_tw_load(tid, 128, p);
+              tw16[tid] = fft_tw_load(tid, 16, p); bh[tid] = fft_bh_load(tid, p));
+        PHASE(ph_fft_r8<false>(tid, 1024, p, s, tw1024[tid]));
+        PHASE(ph_fft_r8<false>(tid, 128, p, s, tw128[tid]));
+        PHASE(ph_fft_r8<false>(tid, 16, p, s, tw16[tid]));
+        PHASE(ph_fft_mid(tid, p, s, bh[tid]));
+        PHASE(ph_fft_r8<true>(tid, 16, p, s, tw16[tid]));
+        PHASE(ph_fft_r8<true>(tid, 128, p, s, tw128[tid]));
+        PHASE(ph_fft_r8<true>(tid, 1024, p, s, tw1024[tid]));
+    };
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        PHASE(ph_spec_load(tid, nt, blk, p, s));
+        round();
+        PHASE(ph_hilb_mid(tid, nt, blk, p, s));
+        round();
+        PHASE(ph_hilb_env(tid, nt, blk, p, s));
+        PHASE(ph_hilb_smooth(tid, nt, blk, p, s));
+        PHASE(ph_hilb_stats1(tid, nt, p, s));
+        PHASE(ph_hilb_dev(tid, nt, blk, p, s));
+        PHASE(ph_hilb_finish(tid, nt, blk, p, s));
+    }
+#undef PHASE
+    return 0;
+}

@@ -356,3 +356,56 @@ def test_envelope_detection_against_oracle(gold_default, eng_default):
             if want >= 0:
                 s = 10 * np.log10(e[want] ** 2 / (np.mean(e[:cfg.min_delay] ** 2) + 1e-10))
                 assert abs(s - snr[f, b]) <= 1e-9 * max(1.0, abs(s))
+
+
+def _full_expect(g):
+    return dict(valid=g["full_valid"], distance=g["full_distance"], snr_db=g["full_snr"],
+                confidence=g["full_confidence"], valid_any=g["full_valid_any"], fused_dist=g["full_fused_dist"],
+                avg_conf=g["full_avg_conf"], kalman=g["full_kalman"])
+
+
+def check_full_records(rec, exp, cfg, nb=3):
+    """Full-chain records against expectations that carry distances instead of indices: the index is recovered
+    from the distance (exact: distance = (peak - (M-1)) / fs * c / 2)."""
+    valid = ((rec["valid_mask"][:, None] >> np.arange(nb)) & 1).astype(bool)
+    assert np.array_equal(valid, exp["valid"])
+    v = exp["valid"]
+    want_idx = np.rint(exp["distance"] * 2 * cfg.FS / cfg.sound_speed).astype(np.int64) + cfg.range_offset
+    assert np.array_equal(rec["peak_idx"][:, :nb][v], want_idx[v])            # bit-exact indices
+    np.testing.assert_allclose(rec["dist"][:, :nb][v], exp["distance"][v], rtol=RTOL)
+    np.testing.assert_allclose(rec["snr_db"][:, :nb][v], exp["snr_db"][v], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(rec["conf"][:, :nb][v], exp["confidence"][v], rtol=RTOL)
+    va = exp["valid_any"]
+    np.testing.assert_allclose(rec["fused_dist"][va], exp["fused_dist"][va], rtol=RTOL)
+    np.testing.assert_allclose(rec["avg_conf"][va], exp["avg_conf"][va], rtol=RTOL)
+    np.testing.assert_allclose(rec["kalman"], exp["kalman"], rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("which", ["default", "distinct"])
+def test_full_chain_against_reference_goldens(which, gold_default, gold_distinct, eng_default, eng_distinct):
+    """_process_band_gpu with its envelope branch (signal_quality, corr envelope peaks, enhanced confidence), fusion
+    and Kalman, against the values the reference itself produced."""
+    from dsp_amd.engine import BatchedKalman
+    g, e = (gold_default, eng_default) if which == "default" else (gold_distinct, eng_distinct)
+    rx = rx_from_i16(g["rx_i16"])
+    q = torch.empty((len(rx), 3, 2), dtype=torch.float64, device=e.device)
+    rec, spec = e.chain(rx, n_streams=1, kalman=BatchedKalman(e, 1), mode="full", quality_out=q)
+    check_full_records(_rec(rec), _full_expect(g), e.cfg)
+    qn = q.cpu().numpy()
+    np.testing.assert_allclose(qn[..., 0], g["signal_quality"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(qn[..., 1], g["corr_quality"], rtol=0, atol=1e-9)
+    check_spectra(spec.cpu().numpy()[g["stage_frames"]], g["stage_spec_db"])
+
+
+def test_full_chain_1024_frames_vs_oracle(eng_default):
+    from dsp_amd.engine import BatchedKalman
+    cfg = eng_default.cfg
+    t = eng_default.tables
+    B, S = 1024, 16
+    rx = synth_frames(B, cfg, t.tx_pcm)
+    o = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=S, mode="full")
+    rec, _ = eng_default.chain(rx, n_streams=S, kalman=BatchedKalman(eng_default, S), mode="full", want_spectra=False)
+    r = _rec(rec)
+    assert np.array_equal(r["peak_idx"][:, :3], o["peak_idx"])
+    check_full_records(r, {k: o[k] for k in ("valid", "distance", "snr_db", "confidence", "valid_any", "fused_dist",
+                                             "avg_conf", "kalman")}, cfg)
