@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
                     help="internal: run the CPU oracle on one frame shard and print the seconds taken")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
+    ap.add_argument("--mode", choices=("named", "full"), default="named",
+                    help="'named': the chain the headline metric names (filter + rfft + first_strong_peak + fusion); "
+                         "'full': with the reference's Hilbert-envelope branch (secondary measurement)")
     ap.add_argument("--workload", choices=("optimized", "original", "realtime"), default="optimized",
                     help="parameter set; the headline line is 'optimized' (airSonar_optimized.py), the others are "
                          "secondary measurements of the variants (airSonar.py, realtime_sonar.py)")
@@ -142,7 +145,7 @@ def main():
     gathered = torch.empty((world * B, 64), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
-        eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=rec, spec_out=spec)
+        eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=rec, spec_out=spec, mode=args.mode)
         if world > 1:
             dist.all_gather_into_tensor(gathered, rec)
 
@@ -193,7 +196,7 @@ def main():
                                    + ("stored" if want_spec else "not stored")
                                    + ", correlate, first_strong_peak, confidence fusion, Kalman over "
                                    f"{S} streams" + (", RCCL all-gather of 64-B result records" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec},
+                       "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "band_kernel", "kernel_ms": kms["band"],

@@ -218,6 +218,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         up(dev_upload(&h->d_ewn, ewn.data(), ewn.size()));
         up(dev_upload(&h->d_ewl, ewl.data(), ewl.size()));
         if (rc == ECHO_OK) rc = env_kernel_prepare(h->ebase);
+        if (const char* st = std::getenv("ECHO_ENV_STOP")) h->ebase.stop_after = std::atoi(st);   // development aid
         h->ebase.roots = h->d_eroots; h->ebase.wn = h->d_ewn; h->ebase.wl = h->d_ewl;
         h->has_env = rc == ECHO_OK;
     }

@@ -9,7 +9,7 @@
 
 namespace echo {
 
-__global__ __launch_bounds__(kEnvNT) void corr_env_kernel(EnvParams p) {
+__global__ __launch_bounds__(kEnvNT, 4) void corr_env_kernel(EnvParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
 #define ECHO_PHASE(...) { __VA_ARGS__; }

@@ -24,6 +24,8 @@ ECHO_HD int env_lds_add(int* p, int v) {
 }
 
 constexpr int kEnvNT = 512;
+constexpr int kEnvIterN = 5;           // n <= kEnvIterN * nt: per-thread trip count of the loops over n, unrolled so
+                                       // that the global loads of all trips are in flight together
 constexpr int kEnvMaxKept = 256;
 constexpr int kEnvChunk = 64;          // prominence scan: per-chunk max/min
 
@@ -45,7 +47,8 @@ struct EnvParams {
     double* env_out;                   // optional [B][nb][L] smoothed envelope
     EnvRes* res_out;                   // [B][nb]
     int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
-    int aux_cmax, aux_cmin, aux_kept;  // byte offsets inside the auxiliary buffer (state[] sits at 0)
+    int aux_cmax, aux_cmin, aux_kept, aux_cand;  // byte offsets inside the auxiliary buffer (state[] sits at 0)
+    int stop_after;                    // development aid: leave the sequence after stage 1..5 (0 = run everything)
 };
 
 struct EnvMisc {
@@ -53,7 +56,7 @@ struct EnvMisc {
     double ss_sm, ss_x, ss_d;                                          // round 2
     double mean_sm, mean_x, mean_d, std_sm, thr;
     double best_val;
-    int n_kept, undecided, best_idx, n_final;
+    int n_kept, undecided, best_idx, n_final, n_cand, pad;
 };
 
 inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
@@ -70,10 +73,12 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     // After the smoothing the buffer that held the raw envelope is reused: first as reduction scratch (7 quantities
     // x nt partials + fold area), then for the candidate states, the per-chunk extrema and the list of kept peaks.
     const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
-    int aux = (L + 15) & ~15;
+    int aux = ((L + 3) & ~3) * 4;                    // int state[L]
     p.aux_cmax = aux; aux += ((nchunk + 1) & ~1) * 8;
     p.aux_cmin = aux; aux += ((nchunk + 1) & ~1) * 8;
     p.aux_kept = aux; aux += kEnvMaxKept * 4;
+    p.aux_cand = aux; aux += (L / 2 + 2) * 4;        // strict local maxima are at least two samples apart
+    if (p.n > kEnvIterN * kEnvNT) return false;
     return off <= 160 * 1024 && p.n * 16 >= (7 * kEnvNT + 7 * 64) * 8 && p.n * 16 >= aux &&
            L / p.distance + 2 <= kEnvMaxKept;
 }
@@ -95,16 +100,34 @@ ECHO_HD cpx<double>* env_buf(unsigned char* s, const EnvParams& p, int which) {
 ECHO_HD EnvMisc* env_misc(unsigned char* s, const EnvParams& p) { return reinterpret_cast<EnvMisc*>(s + p.off_misc); }
 
 // -------------------------------------------------------------------------------- Hilbert transform
-ECHO_HD void ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
+struct EnvPart1 { double v[7]; };       // per-thread partials: sum sm, max sm, min sm, sum x, sum x^2, max|x|, noise sum
+ECHO_HD EnvPart1 ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
     cpx<double>* z = env_buf(smem, p, 0);
     const double* x = p.corr + (size_t)blk * p.L;
-    for (int m = tid; m < p.n; m += nt) z[m] = cpx<double>{x[2 * m], x[2 * m + 1]};
+    EnvPart1 a;
+    a.v[0] = 0.0; a.v[1] = -INFINITY; a.v[2] = INFINITY; a.v[3] = 0.0; a.v[4] = 0.0; a.v[5] = 0.0; a.v[6] = 0.0;
+    cpx<double> xv[kEnvIterN];
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt, mc = m < p.n ? m : p.n - 1;
+        xv[t] = cpx<double>{x[2 * mc], x[2 * mc + 1]};
+    }
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) continue;
+        z[m] = xv[t];
+        const double a0 = fabs(xv[t].x), a1 = fabs(xv[t].y);
+        a.v[3] += xv[t].x + xv[t].y; a.v[4] += xv[t].x * xv[t].x + xv[t].y * xv[t].y;
+        a.v[5] = a0 > a.v[5] ? a0 : a.v[5]; a.v[5] = a1 > a.v[5] ? a1 : a.v[5];
+    }
     cpx<double>* r = reinterpret_cast<cpx<double>*>(smem + p.off_roots);
     for (int i = tid; i < p.plan.nroots; i += nt) r[i] = p.roots[i];
     if (tid == 0) {
         EnvMisc* m = env_misc(smem, p);
-        m->n_kept = 0; m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0;
+        m->n_kept = 0; m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0;
     }
+    return a;
 }
 
 ECHO_HD void ph_env_fft_pass(int tid, int nt, const EnvParams& p, unsigned char* smem, int ps, int src, bool inv) {
@@ -117,11 +140,18 @@ ECHO_HD void ph_env_fft_pass(int tid, int nt, const EnvParams& p, unsigned char*
 ECHO_HD void ph_env_mid(int tid, int nt, const EnvParams& p, unsigned char* smem, int which) {
     cpx<double>* Z = env_buf(smem, p, which);
     const int n = p.n;
-    for (int k = tid; k <= n / 2; k += nt) {
+    constexpr int kIter = (kEnvIterN + 1) / 2;
+    cpx<double> wv[kIter];
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) { const int k = tid + t * nt; wv[t] = p.wl[k <= n / 2 ? k : 0]; }
+#pragma unroll
+    for (int t = 0; t < kIter; ++t) {
+        const int k = tid + t * nt;
+        if (k > n / 2) continue;
         if (k == 0) { Z[0] = cpx<double>{0.0, 0.0}; continue; }
         const int kc = n - k;
         const cpx<double> zk = Z[k], zc = cpx<double>{Z[kc].x, -Z[kc].y};
-        const cpx<double> w = p.wl[k];
+        const cpx<double> w = wv[t];
         // E, O: transforms of the even and odd samples;  X[k] = E + w O,  X[n-k] = conj(E - w O)
         const cpx<double> E{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
         const cpx<double> Bv{0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y)};
@@ -147,10 +177,19 @@ ECHO_HD void ph_env_abs(int tid, int nt, int blk, const EnvParams& p, unsigned c
     double* env = reinterpret_cast<double*>(env_buf(smem, p, which ^ 1));
     const double* x = p.corr + (size_t)blk * p.L;
     const double inv_n = 1.0 / (double)p.n;
-    for (int m = tid; m < p.n; m += nt) {
+    cpx<double> xv[kEnvIterN];
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt, mc = m < p.n ? m : p.n - 1;
+        xv[t] = cpx<double>{x[2 * mc], x[2 * mc + 1]};
+    }
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) continue;
         const cpx<double> h = v[m];
-        env[2 * m] = hypot(x[2 * m], h.x * inv_n);
-        env[2 * m + 1] = hypot(x[2 * m + 1], h.y * inv_n);
+        env[2 * m] = hypot(xv[t].x, h.x * inv_n);
+        env[2 * m + 1] = hypot(xv[t].y, h.y * inv_n);
     }
 }
 
@@ -168,39 +207,40 @@ ECHO_HD void red_fold(int tid, int nt, double* scratch, int K, const int* ops) {
     for (int q = 0; q < K; ++q) {
         double a = scratch[q * nt + tid];
         for (int t = tid + 64; t < nt; t += 64) a = red_op(ops[q], a, scratch[q * nt + t]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the first wavefront finishes the fold with a fixed-order butterfly: every lane ends with the total
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) a = red_op(ops[q], a, __shfl_xor(a, o));
+#endif
         fold[q * 64 + tid] = a;
     }
 }
 ECHO_HD double red_final(const double* scratch, int nt, int K, int q, int op) {
     const double* fold = scratch + K * nt + q * 64;
     double a = fold[0];
+#if !defined(__HIP_DEVICE_COMPILE__)
     const int lim = nt < 64 ? nt : 64;
     for (int t = 1; t < lim; ++t) a = red_op(op, a, fold[t]);
+#endif
     return a;
 }
 
-// sm = uniform_filter1d(env, size) into the other buffer; round-1 partials into... the env buffer is still being
-// read by neighbours, so the partials are kept by the caller and stored in the next phase
-struct EnvPart1 { double v[7]; };
-ECHO_HD EnvPart1 ph_env_smooth(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int env_in) {
+// sm = uniform_filter1d(env, size) into the other buffer; the partials stay with the thread (the raw envelope is
+// still being read by neighbours) and are stored in the next phase
+ECHO_HD void ph_env_smooth(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int env_in, EnvPart1& a) {
     const double* env = reinterpret_cast<const double*>(env_buf(smem, p, env_in));
     double* sm = reinterpret_cast<double*>(env_buf(smem, p, env_in ^ 1));
-    const double* x = p.corr + (size_t)blk * p.L;
     const int h = p.smooth / 2;
-    EnvPart1 a;
-    a.v[0] = 0.0; a.v[1] = -INFINITY; a.v[2] = INFINITY; a.v[3] = 0.0; a.v[4] = 0.0; a.v[5] = 0.0; a.v[6] = 0.0;
     for (int i = tid; i < p.L; i += nt) {
         double s = 0.0;
-        for (int d = -h; d <= h; ++d) s += env[reflect_idx(i + d, p.L)];
+        if (i >= h && i + h < p.L) { for (int d = -h; d <= h; ++d) s += env[i + d]; }
+        else { for (int d = -h; d <= h; ++d) s += env[reflect_idx(i + d, p.L)]; }
         s = s / (double)p.smooth;
         sm[i] = s;
         if (p.env_out) p.env_out[(size_t)blk * p.L + i] = s;
-        const double xv = x[i], ax = fabs(xv);
         a.v[0] += s; a.v[1] = s > a.v[1] ? s : a.v[1]; a.v[2] = s < a.v[2] ? s : a.v[2];
-        a.v[3] += xv; a.v[4] += xv * xv; a.v[5] = ax > a.v[5] ? ax : a.v[5];
         if (i < p.min_delay) a.v[6] += s * s;
     }
-    return a;
 }
 ECHO_HD void ph_env_part1_store(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf, const EnvPart1& a) {
     double* scratch = reinterpret_cast<double*>(env_buf(smem, p, scratch_buf));
@@ -227,26 +267,29 @@ ECHO_HD void ph_env_part1_final(int tid, int nt, const EnvParams& p, unsigned ch
 ECHO_HD void ph_env_part2(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     double* scratch = reinterpret_cast<double*>(env_buf(smem, p, sm_buf ^ 1));
-    const double* x = p.corr + (size_t)blk * p.L;
     const EnvMisc* m = env_misc(smem, p);
-    double a = 0.0, b = 0.0, c = 0.0;
+    const double mean_sm = m->mean_sm, mean_d = m->mean_d;
+    double a = 0.0, c = 0.0;
     for (int i = tid; i < p.L; i += nt) {
-        const double ds = sm[i] - m->mean_sm, dx = x[i] - m->mean_x;
-        a += ds * ds; b += dx * dx;
-        if (i + 1 < p.L) { const double dd = (sm[i + 1] - sm[i]) - m->mean_d; c += dd * dd; }
+        const double ds = sm[i] - mean_sm;
+        a += ds * ds;
+        if (i + 1 < p.L) { const double dd = (sm[i + 1] - sm[i]) - mean_d; c += dd * dd; }
     }
-    scratch[tid] = a; scratch[nt + tid] = b; scratch[2 * nt + tid] = c;
+    scratch[tid] = a; scratch[nt + tid] = c;
 }
 ECHO_HD void ph_env_part2_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
-    const int ops[3] = {0, 0, 0};
-    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 3, ops);
+    const int ops[2] = {0, 0};
+    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 2, ops);
 }
 ECHO_HD void ph_env_part2_final(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
     if (tid != 0) return;
     const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf));
     EnvMisc* m = env_misc(smem, p);
-    m->ss_sm = red_final(scratch, nt, 3, 0, 0); m->ss_x = red_final(scratch, nt, 3, 1, 0);
-    m->ss_d = red_final(scratch, nt, 3, 2, 0);
+    m->ss_sm = red_final(scratch, nt, 2, 0, 0); m->ss_d = red_final(scratch, nt, 2, 1, 0);
+    // sum (x - mean)^2 = sum x^2 - (sum x)^2 / L: the correlation of a band-pass signal has a mean far below its
+    // deviation, so nothing cancels
+    m->ss_x = m->sum_x2 - m->sum_x * m->sum_x / (double)p.L;
+    if (m->ss_x < 0.0) m->ss_x = 0.0;
     m->std_sm = sqrt(m->ss_sm / (double)p.L);
     const double two_std = 2.0 * m->std_sm;
     m->thr = m->mean_sm + two_std;
@@ -254,12 +297,15 @@ ECHO_HD void ph_env_part2_final(int tid, int nt, const EnvParams& p, unsigned ch
 
 // -------------------------------------------------------------------------------- find_peaks
 // state[i]: 0 not a candidate, 1 undecided, 2 kept, 3 removed by the distance rule
+ECHO_HD int* env_state(unsigned char* smem, const EnvParams& p, int sm_buf) {
+    return reinterpret_cast<int*>(env_buf(smem, p, sm_buf ^ 1));
+}
 ECHO_HD unsigned char* env_aux(unsigned char* smem, const EnvParams& p, int sm_buf) {
     return reinterpret_cast<unsigned char*>(env_buf(smem, p, sm_buf ^ 1));
 }
 ECHO_HD void ph_env_candidates(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    unsigned char* state = env_aux(smem, p, sm_buf);
+    int* state = env_state(smem, p, sm_buf);
     double* cmax = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
     double* cmin = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
     for (int i = tid; i < p.L; i += nt) state[i] = 0;
@@ -274,32 +320,40 @@ ECHO_HD void ph_env_candidates(int tid, int nt, const EnvParams& p, unsigned cha
 // local maxima as scipy's _local_maxima_1d: x[i-1] < x[i], plateau x[i..j] equal, x[j+1] < x[i] -> (i + j) // 2
 ECHO_HD void ph_env_maxima(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    unsigned char* state = env_aux(smem, p, sm_buf);
-    const EnvMisc* m = env_misc(smem, p);
+    int* state = env_state(smem, p, sm_buf);
+    int* cand = reinterpret_cast<int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
+    EnvMisc* m = env_misc(smem, p);
     for (int i = tid + 1; i < p.L - 1; i += nt) {
         if (!(sm[i - 1] < sm[i])) continue;
         int j = i;
         while (j + 1 < p.L && sm[j + 1] == sm[i]) ++j;
         if (j + 1 >= p.L || !(sm[j + 1] < sm[i])) continue;
         const int mid = (i + j) / 2;
-        if (sm[mid] >= m->thr) state[mid] = 1;           // height filter: thr <= peak height
+        if (sm[mid] >= m->thr) {                         // height filter: thr <= peak height
+            state[mid] = 1;
+            cand[env_lds_add(&m->n_cand, 1)] = mid;
+        }
     }
 }
 ECHO_HD bool env_higher(const double* sm, int j, int i) { return sm[j] > sm[i] || (sm[j] == sm[i] && j > i); }
-// one round of the distance rule: a candidate is removed when a kept candidate of higher priority lies within
-// distance-1 samples, kept when every higher-priority candidate in that range is already removed
+// one round of the distance rule over the candidate list: a candidate is removed when a kept candidate of higher
+// priority lies within distance-1 samples, kept when every higher-priority candidate in that range is already removed
 ECHO_HD void ph_env_distance_round(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    unsigned char* state = env_aux(smem, p, sm_buf);
+    int* state = env_state(smem, p, sm_buf);
+    const int* cand = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
     EnvMisc* m = env_misc(smem, p);
-    for (int i = tid; i < p.L; i += nt) {
+    const int nc = m->n_cand;
+    for (int t = tid; t < nc; t += nt) {
+        const int i = cand[t];
         if (state[i] != 1) continue;
-        const int lo = i - (p.distance - 1) < 0 ? 0 : i - (p.distance - 1);
-        const int hi = i + (p.distance - 1) >= p.L ? p.L - 1 : i + (p.distance - 1);
         bool removed = false, wait = false;
-        for (int j = lo; j <= hi; ++j) {
-            const unsigned char sj = state[j];
-            if (sj == 0 || sj == 3 || j == i || !env_higher(sm, j, i)) continue;
+        for (int u = 0; u < nc; ++u) {
+            const int j = cand[u];
+            const int d = j > i ? j - i : i - j;
+            if (d == 0 || d >= p.distance) continue;
+            const int sj = state[j];
+            if (sj == 3 || !env_higher(sm, j, i)) continue;
             if (sj == 2) { removed = true; break; }
             wait = true;
         }
@@ -309,13 +363,14 @@ ECHO_HD void ph_env_distance_round(int tid, int nt, const EnvParams& p, unsigned
     }
 }
 ECHO_HD void ph_env_collect(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
-    const unsigned char* state = env_aux(smem, p, sm_buf);
+    const int* state = env_state(smem, p, sm_buf);
+    const int* cand = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
     int* kept = reinterpret_cast<int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
     EnvMisc* m = env_misc(smem, p);
-    for (int i = tid; i < p.L; i += nt)
-        if (state[i] == 2) {
+    for (int t = tid; t < m->n_cand; t += nt)
+        if (state[cand[t]] == 2) {
             const int slot = env_lds_add(&m->n_kept, 1);
-            if (slot < kEnvMaxKept) kept[slot] = i;
+            if (slot < kEnvMaxKept) kept[slot] = cand[t];
         }
 }
 // prominence of each kept peak (scipy _peak_prominences, wlen = None) with chunk-wise skipping; peaks below the
@@ -343,7 +398,7 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     const double* cmax = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
     const double* cmin = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
-    unsigned char* state = env_aux(smem, p, sm_buf);
+    int* state = env_state(smem, p, sm_buf);
     const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
     EnvMisc* m = env_misc(smem, p);
     const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
@@ -361,7 +416,7 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
 ECHO_HD void ph_env_select(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     if (tid != 0) return;
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    const unsigned char* state = env_aux(smem, p, sm_buf);
+    const int* state = env_state(smem, p, sm_buf);
     const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
     EnvMisc* m = env_misc(smem, p);
     const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
@@ -404,20 +459,25 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
 #define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
     do {                                                                                                     \
         PART1_DECL;                                                                                          \
-        PHASE(ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
+        PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
         int cur_ = 0;                                                                                        \
+        if ((p).stop_after == 6) break;                                                                      \
         for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
             PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, false)) SYNC                                  \
             cur_ ^= 1;                                                                                       \
+            if ((p).stop_after == 7 + ps_) break;                                                            \
         }                                                                                                    \
+        if ((p).stop_after >= 7) break;                                                                                                    \
+        if ((p).stop_after == 1) break;                                                                      \
         PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
         for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
             PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, true)) SYNC                                   \
             cur_ ^= 1;                                                                                       \
         }                                                                                                    \
+        if ((p).stop_after == 2) break;                                                                      \
         PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
         cur_ ^= 1;                               /* cur_: envelope */                                        \
-        PHASE(PART1_REF = ph_env_smooth(tid, nt, blk, p, smem, cur_)) SYNC                                   \
+        PHASE(ph_env_smooth(tid, nt, blk, p, smem, cur_, PART1_REF)) SYNC                                   \
         const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \
         PHASE(ph_env_part1_store(tid, nt, p, smem, scr_, PART1_REF)) SYNC                                    \
         PHASE(ph_env_part1_fold(tid, nt, p, smem, scr_)) SYNC                                                \
@@ -425,6 +485,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         PHASE(ph_env_part2(tid, nt, blk, p, smem, sm_)) SYNC                                                 \
         PHASE(ph_env_part2_fold(tid, nt, p, smem, scr_)) SYNC                                                \
         PHASE(ph_env_part2_final(tid, nt, p, smem, scr_)) SYNC                                               \
+        if ((p).stop_after == 3) break;                                                                      \
         PHASE(ph_env_candidates(tid, nt, p, smem, sm_)) SYNC                                                 \
         PHASE(ph_env_maxima(tid, nt, p, smem, sm_)) SYNC                                                     \
         for (int round_ = 0; round_ < (p).L; ++round_) {                                                     \
@@ -436,6 +497,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         }                                                                                                    \
         PHASE(ph_env_collect(tid, nt, p, smem, sm_)) SYNC                                                         \
         PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
+        if ((p).stop_after == 5) break;                                                                      \
         PHASE(ph_env_select(tid, nt, p, smem, sm_)) SYNC                                                     \
         PHASE(ph_env_finish(tid, blk, p, smem))                                                              \
     } while (0)

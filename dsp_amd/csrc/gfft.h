@@ -2,8 +2,8 @@
 // order in and out), float or double.  Used where the length has no large power-of-two structure: the Hilbert
 // transform of the 4556-sample correlation (n = 2278 = 67*17*2, float64) and the spectrum of long frames
 // (n = 4410 = 7*7*5*3*3*2, float32).  Each pass of radix r is evaluated output by output as an r-term sum with the
-// r-th roots of unity (cost n*r complex multiply-adds per pass), four outputs of one butterfly per work item so an
-// input element is read once per four outputs; the inter-pass twiddles W_n^(s*k*m) are applied when a pass stores
+// r-th roots of unity, outputs q and r-q sharing their sums (n*r/2 complex multiply-adds per pass); the inter-pass
+// twiddles W_n^(s*k*m) are applied when a pass stores
 // its outputs.  Plain C++: phases of (tid, nt) as in band_phases.h.
 #pragma once
 #include <math.h>
@@ -24,10 +24,11 @@ struct GfftPlan {
     int radix[kGfftMaxPass];     // largest first: the first pass needs no twiddles
     int lp[kGfftMaxPass];        // product of the radices of the earlier passes
     int root_off[kGfftMaxPass];  // offset of the pass's r roots exp(-2*pi*i*t/r) in the roots table
+    int pairs[kGfftMaxPass];     // conjugate output pairs per wavefront item (1..4), chosen for nt threads
     int nroots;
 };
 
-inline bool gfft_plan(GfftPlan& pl, int n) {
+inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512) {
     pl.n = n; pl.npass = 0; pl.nroots = 0;
     if (n < 1) return false;
     int fac[32], nf = 0, rem = n;
@@ -48,6 +49,15 @@ inline bool gfft_plan(GfftPlan& pl, int n) {
     for (int i = 0; i < no; ++i) {
         pl.radix[i] = out[i]; pl.lp[i] = lp; pl.root_off[i] = pl.nroots;
         pl.nroots += out[i]; lp *= out[i];
+        // pairs per wavefront item: fewest rounds over the nt/64 wavefronts, weighted by the work per item
+        const int npair = out[i] / 2 + 1, nchunk = (n / out[i] + 63) / 64, nw = nt / 64 > 0 ? nt / 64 : 1;
+        int best = 1, best_cost = 1 << 30;
+        for (int P = 1; P <= 4; ++P) {
+            const int items = ((npair + P - 1) / P) * nchunk;
+            const int cost = ((items + nw - 1) / nw) * (P + 1);      // + 1: the input read and loop overhead
+            if (cost < best_cost) { best_cost = cost; best = P; }
+        }
+        pl.pairs[i] = best;
     }
     pl.npass = no;
     return true;
@@ -72,56 +82,129 @@ template <class T> inline void gfft_tables(const GfftPlan& pl, std::vector<cpx<T
 ECHO_HD float gf_fma(float a, float b, float c) { return fmaf(a, b, c); }
 ECHO_HD double gf_fma(double a, double b, double c) { return fma(a, b, c); }
 
-// One pass.  in/out: LDS buffers of n elements (distinct).  roots: this pass's r roots (LDS or global).
-// wn: global table of n twiddles, used to pre-multiply the outputs for the next pass.  inv: conjugate transform.
-template <class T>
-ECHO_HD void gfft_pass(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
-                       const cpx<T>* wn, bool inv) {
-    constexpr int Q = 4;
+// One pass.  in/out: LDS buffers of n elements (distinct).  roots: this pass's r roots (LDS).  wn: global table of
+// n twiddles, used to pre-multiply the outputs for the next pass.  inv: conjugate transform.
+//
+// A pass of radix r is the product of the r x r root matrix with the r x (n/r) matrix of its butterflies' inputs.
+// Outputs q and r-q of a butterfly use conjugate roots, so they share four real sums over the inputs v_s and roots
+// w = W_r^(s*q):  A = sum v.x w.x, B = sum v.y w.y, C = sum v.x w.y, D = sum v.y w.x;
+//   out[q] = (A - B) + i (C + D),  out[r-q] = (A + B) + i (D - C)   (swapped for the inverse transform);
+// q = 0 (and q = r/2 for even r) pair with themselves.  A wavefront takes P such pairs for 64 butterflies (one per
+// lane): the root indices are the same for all its lanes, so their arithmetic is scalar and the root reads are
+// LDS broadcasts; per input element a lane reads one input and issues 4P multiply-adds.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ECHO_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define ECHO_WAVE_UNIFORM(x) (x)
+#endif
+
+template <class T, int P>
+ECHO_HD void gfft_pass_p(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
+                         const cpx<T>* wn, bool inv) {
     const int r = pl.radix[ps], Lp = pl.lp[ps], m = pl.n / (Lp * r);
-    const int nqb = (r + Q - 1) / Q, cols = Lp * m, items = nqb * cols;
+    const int npair = r / 2 + 1, npb = (npair + P - 1) / P, cols = Lp * m, nchunk = (cols + 63) / 64;
     const bool last = ps + 1 >= pl.npass;
-    const int r2 = last ? 1 : pl.radix[ps + 1];
-    const int m2 = last ? 1 : pl.n / (pl.lp[ps + 1] * r2);
-    for (int it = tid; it < items; it += nt) {
-        const int qb = it / cols, c = it - qb * cols;
+    const int m2 = last ? 1 : pl.n / (pl.lp[ps + 1] * pl.radix[ps + 1]);
+    const int wave = ECHO_WAVE_UNIFORM(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    for (int wi = wave; wi < npb * nchunk; wi += nw) {
+        const int pb = wi / nchunk, chunk = wi - pb * nchunk;
+        const int craw = chunk * 64 + lane;
+        const bool active = craw < cols;
+        const int c = active ? craw : cols - 1;
         const int k = c / m, j = c - k * m;
-        const int q0 = qb * Q;
-        int idx[Q], step[Q];
-        cpx<T> acc[Q];
+        const int t0 = pb * P;
+        int idx[P], step[P];
+        T A[P], B[P], C[P], D[P];
+        cpx<T> wa[P], wb[P];
 #pragma unroll
-        for (int u = 0; u < Q; ++u) {
-            idx[u] = 0; step[u] = q0 + u < r ? q0 + u : 0;
-            acc[u].x = (T)0; acc[u].y = (T)0;
+        for (int u = 0; u < P; ++u) {
+            step[u] = t0 + u < npair ? t0 + u : 0;
+            A[u] = B[u] = C[u] = D[u] = (T)0;
+            wa[u] = roots[0];                               // s = 0
+            wb[u] = roots[step[u]];                         // s = 1 (step < r)
+            idx[u] = 2 * step[u];                           // s = 2
+            if (idx[u] >= r) idx[u] -= r;
         }
-        const cpx<T>* src = in + k * (m * r) + j;
-        for (int s = 0; s < r; ++s) {
-            const cpx<T> v = src[m * s];
+        // twiddle the next pass wants on this butterfly's outputs: position p = (k + Lp*q)*m + j is read there as
+        // (k2, s2, j2) with k2 = k + Lp*q and s2 = j / m2, and needs W_n^(s2*k2*m2); fetched now, used after the loop
+        const int s2m2 = last ? 0 : (j / m2) * m2;
+        cpx<T> tw[2 * P];
 #pragma unroll
-            for (int u = 0; u < Q; ++u) {
-                const cpx<T> w = roots[idx[u]];
-                const T wy = inv ? -w.y : w.y;
-                acc[u].x = gf_fma(v.x, w.x, acc[u].x); acc[u].x = gf_fma(-v.y, wy, acc[u].x);
-                acc[u].y = gf_fma(v.x, wy, acc[u].y);  acc[u].y = gf_fma(v.y, w.x, acc[u].y);
+        for (int u = 0; u < P; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = step[u], qe = (e && q) ? r - q : q;
+                tw[2 * u + e] = last ? cpx<T>{(T)1, (T)0} : wn[s2m2 * (k + Lp * qe)];
+            }
+        const cpx<T>* src = in + k * (m * r) + j;
+        // two elements in flight: the reads that refill one (input element and roots) are issued right after its
+        // multiply-adds and have the other's multiply-adds to complete
+        cpx<T> va = src[0], vb = src[r > 1 ? m : 0];
+        int s = 0;
+        for (; s + 1 < r; s += 2) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(va.x, wa[u].x, A[u]); B[u] = gf_fma(va.y, wa[u].y, B[u]);
+                C[u] = gf_fma(va.x, wa[u].y, C[u]); D[u] = gf_fma(va.y, wa[u].x, D[u]);
+            }
+            va = src[m * (s + 2 < r ? s + 2 : r - 1)];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                wa[u] = roots[idx[u]];
+                idx[u] += step[u];
+                if (idx[u] >= r) idx[u] -= r;
+            }
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(vb.x, wb[u].x, A[u]); B[u] = gf_fma(vb.y, wb[u].y, B[u]);
+                C[u] = gf_fma(vb.x, wb[u].y, C[u]); D[u] = gf_fma(vb.y, wb[u].x, D[u]);
+            }
+            vb = src[m * (s + 3 < r ? s + 3 : r - 1)];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                wb[u] = roots[idx[u]];
                 idx[u] += step[u];
                 if (idx[u] >= r) idx[u] -= r;
             }
         }
+        if (s < r) {                                        // odd radix: last element
 #pragma unroll
-        for (int u = 0; u < Q; ++u) {
-            if (q0 + u >= r) continue;
-            const int p = (k + Lp * (q0 + u)) * m + j;
-            cpx<T> a = acc[u];
-            if (!last) {
-                // the next pass reads position p as (k2, s2, j2) and needs it multiplied by W_n^(s2*k2*m2)
-                const int s2 = (p / m2) % r2, k2 = p / (m2 * r2);
-                const cpx<T> w = wn[s2 * k2 * m2];
-                const T wy = inv ? -w.y : w.y;
-                const T re = a.x * w.x - a.y * wy, im = a.x * wy + a.y * w.x;
-                a.x = re; a.y = im;
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(va.x, wa[u].x, A[u]); B[u] = gf_fma(va.y, wa[u].y, B[u]);
+                C[u] = gf_fma(va.x, wa[u].y, C[u]); D[u] = gf_fma(va.y, wa[u].x, D[u]);
             }
-            out[p] = a;
         }
+        if (!active) continue;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int q = t0 + u;
+            if (q >= npair) continue;
+            cpx<T> o[2];
+            o[0].x = A[u] - B[u]; o[0].y = C[u] + D[u];       // root w
+            o[1].x = A[u] + B[u]; o[1].y = D[u] - C[u];       // root conj(w)
+            const int nout = (q == 0 || r - q == q) ? 1 : 2;
+            for (int e = 0; e < nout; ++e) {
+                cpx<T> a = o[inv ? 1 - e : e];
+                if (!last) {
+                    const cpx<T> t = tw[2 * u + e];
+                    const T wy = inv ? -t.y : t.y;
+                    const T re = a.x * t.x - a.y * wy, im = a.x * wy + a.y * t.x;
+                    a.x = re; a.y = im;
+                }
+                out[(k + Lp * (e ? r - q : q)) * m + j] = a;
+            }
+        }
+    }
+}
+
+template <class T>
+ECHO_HD void gfft_pass(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
+                       const cpx<T>* wn, bool inv) {
+    switch (pl.pairs[ps]) {
+        case 1: gfft_pass_p<T, 1>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+        case 2: gfft_pass_p<T, 2>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+        case 3: gfft_pass_p<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+        default: gfft_pass_p<T, 4>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
     }
 }
 

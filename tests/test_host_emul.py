@@ -124,3 +124,59 @@ def test_emulated_long_frame_path(emul, gold_original):
     assert np.array_equal(peak[0], g["peak_idx"][0])
     want = g["stage_corr0"].copy(); want[:, cfg.half:cfg.half + cfg.min_delay] = 0
     assert np.array_equal(c0[0], want)
+
+
+def test_emulated_generic_fft():
+    subprocess.check_call(["make", "-C", EMUL], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(EMUL, "libemul.so"))
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.emul_gfft.argtypes = [I, I, I, P, P]
+    rng = np.random.default_rng(0)
+    for n in (2278, 4410, 2205, 64, 17, 6, 4, 3, 2, 1):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        xin = np.ascontiguousarray(np.stack([x.real, x.imag], -1))
+        for inv in (0, 1):
+            ref = np.fft.ifft(x) * n if inv else np.fft.fft(x)
+            for use_float, tol in ((0, 5e-15), (1, 1e-6)):
+                out = np.zeros((n, 2))
+                assert lib.emul_gfft(n, inv, use_float, _ptr(xin), _ptr(out)) > 0
+                assert np.abs(out[:, 0] + 1j * out[:, 1] - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_emulated_envelope_branch(emul, gold_default):
+    """Correlation envelope branch (float64 Hilbert by mixed-radix FFT, uniform_filter1d(5), find_peaks with height,
+    distance and prominence, peak choice, SNR, corr_quality) and the band-signal quality that rides on the spectrum
+    kernel, thread by thread on the host, against SciPy (through the oracle) and the goldens."""
+    from oracle import echo_oracle as O
+    g = gold_default
+    cfg = C.optimized_config()
+    t = build_tables(cfg)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_env.argtypes = [I, I, I, I, P, I, P, P, P, P, P, P]
+    corr = np.ascontiguousarray(g["stage_corr"][:6])
+    B, nb, L = corr.shape
+    env = np.zeros_like(corr); peak = np.zeros((B, nb), np.int32); npk = np.zeros((B, nb), np.int32)
+    snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); q = np.zeros((B, nb))
+    assert emul.emul_env(L, nb, cfg.min_delay, 5, _ptr(corr), B, _ptr(env), _ptr(peak), _ptr(snr), _ptr(amp), _ptr(q),
+                         _ptr(npk)) == 0
+    ref = g["stage_corr_envelope"][:6].astype(np.float64)
+    assert np.abs(env - ref).max() <= 2e-7 * np.abs(ref).max()
+    for f in range(B):
+        for b in range(nb):
+            e, pk, qual = O.gpu_envelope_detection(corr[f, b], 5)
+            assert np.abs(env[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
+            vp = pk[pk >= cfg.min_delay]
+            want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
+            assert (want, len(pk)) == (peak[f, b], npk[f, b])
+            assert abs(qual - q[f, b]) <= 1e-9 and amp[f, b] == np.abs(corr[f, b]).max()
+    # signal_quality from the float32 spectrum kernel with the second Bluestein round
+    emul.emul_spec_hilbert.argtypes = [I, I, I, I, P, P, P, I, P, P]
+    band = np.ascontiguousarray(g["stage_band_sig"][:4].astype(np.float32))
+    spec = np.zeros((4, nb, cfg.n_bins), np.float32); sq = np.zeros((4, nb))
+    taps = np.ascontiguousarray(t.taps); chirps = np.ascontiguousarray(t.chirps)
+    assert emul.emul_spec_hilbert(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(taps), _ptr(chirps), _ptr(band), 4,
+                                  _ptr(spec), _ptr(sq)) == 0
+    np.testing.assert_allclose(sq, g["signal_quality"][g["stage_frames"][:4]], rtol=0, atol=2e-6)
+    lin, rl = 10 ** (spec.astype(np.float64) / 20), 10 ** (g["stage_spec_db"][:4].astype(np.float64) / 20)
+    live = rl.max(axis=-1) > 1e-9
+    assert ((np.abs(lin - rl).max(axis=-1) / np.maximum(rl.max(axis=-1), 1e-300))[live] <= 1e-5).all()
