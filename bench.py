@@ -139,7 +139,7 @@ def main():
     S = N_STREAMS if B % N_STREAMS == 0 else 1
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
-    want_spec = not args.no_spectra and args.workload != "original"     # no spectrum kernel for 8820-sample frames yet
+    want_spec = not args.no_spectra
     rec = torch.empty((B, 64), dtype=torch.uint8, device=dev)
     spec = torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
     gathered = torch.empty((world * B, 64), dtype=torch.uint8, device=dev) if world > 1 else None

@@ -26,6 +26,7 @@ struct EchoHandle {
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
     float2* d_uk = nullptr;
+    cpx<float> *d_lroots = nullptr, *d_lwn = nullptr, *d_luk = nullptr;   // long path: spectrum FFT tables
     bool long_path = false;                // frame too long for one workgroup, or the MAD detector: tiled kernels
     LongParams lbase;
     // device constant tables
@@ -207,7 +208,19 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         up(dev_upload(&h->d_uk, t.uk.data(), t.uk.size()));
         if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
     } else if (rc == ECHO_OK) {
-        rc = long_kernels_prepare(h->lbase);
+        if (h->lbase.has_spec) {
+            std::vector<cpx<float>> lr, lw, lu(h->lbase.n2 + 1);
+            gfft_tables(h->lbase.splan, lr, lw);
+            for (int k = 0; k <= h->lbase.n2; ++k) {
+                const double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)h->lbase.N;
+                lu[k] = cpx<float>{(float)std::cos(ang), (float)std::sin(ang)};
+            }
+            up(dev_upload(&h->d_lroots, lr.data(), lr.size()));
+            up(dev_upload(&h->d_lwn, lw.data(), lw.size()));
+            up(dev_upload(&h->d_luk, lu.data(), lu.size()));
+            h->lbase.sroots = h->d_lroots; h->lbase.swn = h->d_lwn; h->lbase.suk = h->d_luk;
+        }
+        if (rc == ECHO_OK) rc = long_kernels_prepare(h->lbase);
     }
     std::memset(&h->ebase, 0, sizeof(h->ebase));
     if (rc == ECHO_OK && !h->long_path &&
@@ -237,7 +250,7 @@ void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
-                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk};
+                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -324,7 +337,15 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
 
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
     if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
-    if (h->long_path) return ECHO_ERR_UNSUPPORTED;
+    if (h->long_path) {
+        for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
+            LongParams q = h->lbase;
+            q.spec_db = db ? 1 : 0;
+            q.spec_in = band_sig + (size_t)f0 * q.nb * q.N; q.spec_out = spec + (size_t)f0 * q.nb * q.nbins;
+            if (int rc = launch_long_spec(q, std::min(h->max_chunk, B - f0), static_cast<hipStream_t>(stream))) return rc;
+        }
+        return ECHO_OK;
+    }
     BandParams p = h->base;
     p.spec_db = db ? 1 : 0; p.specd_in = band_sig; p.spec_out = spec;
     return launch_spec(p, B, static_cast<hipStream_t>(stream));
@@ -442,7 +463,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     const bool kal = kalman_x || kalman_p || kalman_init;
     if (kal && (!kalman_x || !kalman_p || !kalman_init || n_streams < 1 || B % n_streams != 0)) return ECHO_ERR_INVALID;
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
-    if (h->long_path && spec_db) return ECHO_ERR_UNSUPPORTED;
+    if (h->long_path && spec_db && !h->lbase.has_spec) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands, N = h->cfg.n_rx;
     // frames are processed in passes of at most max_chunk; with a Kalman state each pass must hold whole
@@ -475,6 +496,11 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             q.det_io = h->d_pos; q.det_stride = q.L - q.half; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
             rc = launch_long_detect(q, n, s);
             if (rc) return rc;
+            if (spec_db) {
+                q.spec_db = 1; q.spec_in = h->d_band; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
+                rc = launch_long_spec(q, n, s);
+                if (rc) return rc;
+            }
         } else if (full) {
             // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
             BandParams p = h->base;
@@ -491,7 +517,9 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             if (rc) return rc;
         }
         if (prof) (void)hipEventRecord(ev[2], s);
-        if (full) {
+        if (h->long_path) {
+            // spectra of long frames are written by the long-path branch above
+        } else if (full) {
             BandParams q = h->base;
             q.spec_db = 1; q.specf_in = h->d_bandf; q.sq_out = h->d_sq;
             q.spec_out = spec_db ? spec_db + (size_t)f0 * nb * q.nbins : h->d_spec;

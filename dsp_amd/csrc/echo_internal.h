@@ -54,6 +54,7 @@ int long_kernels_prepare(const LongParams& p);
 int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <= 65535 per launch
 int launch_long_corr(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
+int launch_long_spec(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);
 int launch_corr_env(const EnvParams& p, int B, hipStream_t s);
 int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,

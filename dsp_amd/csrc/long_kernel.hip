@@ -35,6 +35,20 @@ __global__ __launch_bounds__(kLDetNT) void long_detect_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
+__global__ __launch_bounds__(kLSpecNT) void long_spec_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    ph_lspec_load(tid, kLSpecNT, blk, p, smem);
+    __syncthreads();
+    int cur = 0;
+    for (int ps = 0; ps < p.splan.npass; ++ps) {
+        ph_lspec_pass(tid, kLSpecNT, p, smem, ps, cur);
+        __syncthreads();
+        cur ^= 1;
+    }
+    ph_lspec_store(tid, kLSpecNT, blk, p, smem, cur);
+}
+
 static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP; }
 
 int long_kernels_prepare(const LongParams& p) {
@@ -43,7 +57,9 @@ int long_kernels_prepare(const LongParams& p) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             p.corr_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(long_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            p.det_smem) != hipSuccess)
+                            p.det_smem) != hipSuccess ||
+        (p.has_spec && hipFuncSetAttribute(reinterpret_cast<const void*>(long_spec_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, p.spec_smem) != hipSuccess))
         return ECHO_ERR_HIP;
     return ECHO_OK;
 }
@@ -64,6 +80,13 @@ int launch_long_corr(const LongParams& p, int B, hipStream_t s) {
     if (nblk > 65535 || p.k_begin < 0 || p.k_begin >= p.L) return ECHO_ERR_INVALID;
     const int tiles = (p.L - p.k_begin + kLCorrNT * kR - 1) / (kLCorrNT * kR);
     hipLaunchKernelGGL(long_corr_kernel, dim3(tiles, nblk), dim3(kLCorrNT), p.corr_smem, s, p);
+    return ok();
+}
+
+int launch_long_spec(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!p.has_spec || !p.spec_in || !p.spec_out) return ECHO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(long_spec_kernel, dim3(B * p.nb), dim3(kLSpecNT), p.spec_smem, s, p);
     return ok();
 }
 

@@ -7,6 +7,7 @@
 // thread.  Plain C++ apart from the two LDS atomics.
 #pragma once
 #include "band_phases.h"
+#include "gfft.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ECHO_LDS_ADD(p, v) atomicAdd((p), (v))
@@ -21,6 +22,7 @@ namespace echo {
 constexpr int kLFirNT = 256;                   // threads per FIR workgroup: kLFirNT*kR outputs per tile
 constexpr int kLCorrNT = 768;                  // threads per correlation workgroup: kLCorrNT*kR outputs per tile
 constexpr int kLDetNT = 1024;                  // threads per detector workgroup
+constexpr int kLSpecNT = 512;                  // threads per spectrum workgroup
 constexpr int kLPad = 64 * kR + 2 * kR;        // zero margin either side of the LDS signal: one wavefront's spread of
                                                // first outputs (64*kR) plus the window prefetch (2*kR)
 
@@ -45,8 +47,16 @@ struct LongParams {
     long long det_stride;
     int det_off, write_mutated;
     BandRes* res_out;                // [B][nb]
+    // spectrum: rfft of the N-sample band signal as a packed complex FFT of length N/2 (gfft.h), float32
+    int has_spec, n2, nbins, spec_db;
+    GfftPlan splan;
+    const cpx<float>* sroots;        // global: splan.nroots
+    const cpx<float>* swn;           // global: n2 twiddles
+    const cpx<float>* suk;           // global: n2 + 1, exp(-2*pi*i*k/N)
+    const double* spec_in;           // [B][nb][N]
+    float* spec_out;                 // [B][nb][nbins]
     // LDS sizes
-    int fir_smem, corr_smem, det_smem;
+    int fir_smem, corr_smem, det_smem, spec_smem;
 };
 
 struct DetMisc {                     // detector scalars in LDS
@@ -65,7 +75,43 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.corr_smem = (N + 2 * kLPad) * 8 + (p.mgroups + 1) * kR * 8;
     const int npos = p.L - p.half;
     p.det_smem = ((npos + 1) & ~1) * 8 + 256 * 4 + (int)sizeof(DetMisc);
+    p.n2 = N / 2; p.nbins = N / 2 + 1;
+    p.has_spec = (N % 2 == 0) && gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
+    p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
+    if (p.spec_smem > 160 * 1024) p.has_spec = 0;
     return p.fir_smem <= 160 * 1024 && p.corr_smem <= 160 * 1024 && p.det_smem <= 160 * 1024;
+}
+
+// ---------------------------------------------------------------- spectrum of a long frame
+// mag2db(np.fft.rfft(band_sig)) (airSonar.py:141-142): Z = FFT_n2(x[2m] + i x[2m+1]);
+// X[k] = E + u_k O with E = (Z[k] + conj Z[n2-k]) / 2, O = -i (Z[k] - conj Z[n2-k]) / 2, u_k = exp(-2 pi i k / N).
+// LDS: two buffers of n2 complex floats, then the roots.
+ECHO_HD void ph_lspec_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    cpx<float>* z = reinterpret_cast<cpx<float>*>(smem);
+    const double* x = p.spec_in + (size_t)blk * p.N;
+    for (int m = tid; m < p.n2; m += nt) z[m] = cpx<float>{(float)x[2 * m], (float)x[2 * m + 1]};
+    cpx<float>* r = z + 2 * p.n2;
+    for (int i = tid; i < p.splan.nroots; i += nt) r[i] = p.sroots[i];
+}
+ECHO_HD void ph_lspec_pass(int tid, int nt, const LongParams& p, unsigned char* smem, int ps, int src) {
+    cpx<float>* b0 = reinterpret_cast<cpx<float>*>(smem);
+    const cpx<float>* r = b0 + 2 * p.n2 + p.splan.root_off[ps];
+    gfft_pass<float>(tid, nt, p.splan, ps, b0 + (src ? p.n2 : 0), b0 + (src ? 0 : p.n2), r, p.swn, false);
+}
+ECHO_HD void ph_lspec_store(int tid, int nt, int blk, const LongParams& p, unsigned char* smem, int which) {
+    const cpx<float>* Z = reinterpret_cast<const cpx<float>*>(smem) + (which ? p.n2 : 0);
+    for (int k = tid; k < p.nbins; k += nt) {
+        const int ka = k == p.n2 ? 0 : k, kb = (k == 0 || k == p.n2) ? 0 : p.n2 - k;
+        const cpx<float> zk = Z[ka], zc = cpx<float>{Z[kb].x, -Z[kb].y};
+        const cpx<float> u = p.suk[k];
+        const float ex = 0.5f * (zk.x + zc.x), ey = 0.5f * (zk.y + zc.y);
+        const float bx = 0.5f * (zk.x - zc.x), by = 0.5f * (zk.y - zc.y);
+        const float ox = by, oy = -bx;                                     // -i (Z - conj Z') / 2
+        const float xr = ex + (u.x * ox - u.y * oy), xi = ey + (u.x * oy + u.y * ox);
+        float mag = sqrtf(xr * xr + xi * xi);
+        if (p.spec_db) mag = 20.0f * log10f(fmaxf(mag, 1e-12f));
+        p.spec_out[(size_t)blk * p.nbins + k] = mag;
+    }
 }
 
 // ---------------------------------------------------------------- FIR 'same', one tile of kLFirNT*kR outputs

@@ -225,3 +225,31 @@ extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps
 #undef PHASE
     return 0;
 }
+
+// Spectrum of long frames (long_phases.h: packed real FFT through gfft.h, float32).
+extern "C" int emul_long_spec(int N, int M, int K, int nb, const double* band, int B, float* spec_out) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, 0, 1) || !p.has_spec) return -2;
+    std::vector<cpx<float>> roots, wn, uk(p.n2 + 1);
+    gfft_tables(p.splan, roots, wn);
+    for (int k = 0; k <= p.n2; ++k) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;
+        uk[k] = cpx<float>{(float)std::cos(a), (float)std::sin(a)};
+    }
+    p.sroots = roots.data(); p.swn = wn.data(); p.suk = uk.data();
+    p.spec_db = 1; p.spec_in = band; p.spec_out = spec_out;
+    std::vector<unsigned char> smem(p.spec_smem);
+    unsigned char* s = smem.data();
+    const int nt = kLSpecNT;
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        PHASE(ph_lspec_load(tid, nt, blk, p, s));
+        int cur = 0;
+        for (int ps = 0; ps < p.splan.npass; ++ps) { PHASE(ph_lspec_pass(tid, nt, p, s, ps, cur)); cur ^= 1; }
+        PHASE(ph_lspec_store(tid, nt, blk, p, s, cur));
+    }
+#undef PHASE
+    return 0;
+}

@@ -244,9 +244,8 @@ def test_original_variant_goldens_and_oracle(gold_original):
     e = _engine(cfg)
     from dsp_amd.engine import BatchedKalman
     rx = rx_from_i16(g["rx_i16"])
-    rec, spec = e.chain(rx, n_streams=1, kalman=BatchedKalman(e, 1), want_spectra=False)
+    rec, spec = e.chain(rx, n_streams=1, kalman=BatchedKalman(e, 1), want_spectra=True)
     r = _rec(rec)
-    assert spec is None
     assert np.array_equal(r["peak_idx"], g["peak_idx"])
     valid = ((r["valid_mask"][:, None] >> np.arange(3)) & 1).astype(bool)
     assert np.array_equal(valid, g["valid"])
@@ -259,6 +258,9 @@ def test_original_variant_goldens_and_oracle(gold_original):
     band = e.bandpass_bank(rx[:1])
     ref = g["stage_band_sig0"]
     assert (np.abs(band[0].cpu().numpy() - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-12
+    ref_db = 20 * np.log10(np.maximum(np.abs(np.fft.rfft(g["stage_band_sig0"], axis=-1)), 1e-12))
+    check_spectra(spec[0].cpu().numpy(), ref_db)                      # spectra written by the chain
+    check_spectra(e.spectrum(band)[0].cpu().numpy(), ref_db)          # and by the standalone entry point
     corr = e.correlate(band)
     ref = g["stage_corr0"]
     assert (np.abs(corr[0].cpu().numpy() - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-7

@@ -124,6 +124,14 @@ def test_emulated_long_frame_path(emul, gold_original):
     assert np.array_equal(peak[0], g["peak_idx"][0])
     want = g["stage_corr0"].copy(); want[:, cfg.half:cfg.half + cfg.min_delay] = 0
     assert np.array_equal(c0[0], want)
+    # dB spectrum of the 8820-sample band signal (packed real FFT of length 4410 = 7*7*5*3*3*2, float32)
+    emul.emul_long_spec.argtypes = [I, I, I, I, P, I, P]
+    bs = np.ascontiguousarray(g["stage_band_sig0"][None])
+    spec = np.zeros((1, nb, N // 2 + 1), np.float32)
+    assert emul.emul_long_spec(N, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(bs), 1, _ptr(spec)) == 0
+    ref = np.abs(np.fft.rfft(bs[0], axis=-1))
+    lin = 10 ** (spec[0].astype(np.float64) / 20)
+    assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
 
 
 def test_emulated_generic_fft():
