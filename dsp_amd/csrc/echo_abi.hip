@@ -296,6 +296,7 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
 }
 
 int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
         for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
@@ -311,6 +312,7 @@ int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stre
 }
 
 int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !band_sig || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
@@ -336,6 +338,7 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
 }
 
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
         for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
@@ -357,6 +360,7 @@ int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
 }
 
 int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !band_sig || !corr || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
         for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
@@ -374,6 +378,7 @@ int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, v
 
 int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db, double* amplitude,
                            int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !corr || !peak_idx || !snr_db || B < 0) return ECHO_ERR_INVALID;
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -403,6 +408,7 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
 
 int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
                             double* quality, int32_t* n_peaks, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !corr || B < 0) return ECHO_ERR_INVALID;
     if (!h->has_env) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -430,6 +436,7 @@ int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream) {
 
 int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* snr_db, const double* amplitude,
                          EchoResult* out, int B, void* stream) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !peak_idx || !snr_db || !amplitude || !out || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands;
@@ -458,6 +465,7 @@ int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
                       double* quality) {
+    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) return ECHO_ERR_UNSUPPORTED;
     const bool kal = kalman_x || kalman_p || kalman_init;

@@ -411,3 +411,21 @@ def test_full_chain_1024_frames_vs_oracle(eng_default):
     assert np.array_equal(r["peak_idx"][:, :3], o["peak_idx"])
     check_full_records(r, {k: o[k] for k in ("valid", "distance", "snr_db", "confidence", "valid_any", "fused_dist",
                                              "avg_conf", "kalman")}, cfg)
+
+
+@pytest.mark.parametrize("mode", ["named", "full"])
+def test_ragged_and_empty_batches(mode, eng_default):
+    """Batch sizes that do not fill a tile (IIR tiles hold 16 or 64 frames), a single frame and an empty batch give
+    the per-frame results of the same frames inside a larger batch."""
+    cfg = eng_default.cfg
+    rx = synth_frames(130, cfg, eng_default.tables.tx_pcm)
+    ref, ref_spec = eng_default.chain(rx, mode=mode)
+    ref = ref.cpu().numpy(); ref_spec = ref_spec.cpu().numpy()
+    for B in (0, 1, 17, 65, 129):
+        rec, spec = eng_default.chain(rx[:B], mode=mode)
+        assert rec.shape == (B, 64) and spec.shape == (B, 3, cfg.n_bins)
+        assert np.array_equal(rec.cpu().numpy(), ref[:B]), B
+        assert np.array_equal(spec.cpu().numpy(), ref_spec[:B]), B
+    empty = eng_default.bandpass_bank(rx[:0])
+    assert empty.shape == (0, 3, cfg.n_rx)
+    assert eng_default.correlate(empty).shape == (0, 3, cfg.n_corr)
