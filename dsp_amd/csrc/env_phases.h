@@ -26,7 +26,6 @@ ECHO_HD int env_lds_add(int* p, int v) {
 constexpr int kEnvNT = 512;
 constexpr int kEnvIterN = 5;           // n <= kEnvIterN * nt: per-thread trip count of the loops over n, unrolled so
                                        // that the global loads of all trips are in flight together
-constexpr int kEnvMaxKept = 256;
 constexpr int kEnvChunk = 64;          // prominence scan: per-chunk max/min
 
 struct EnvRes {                        // per (frame, band)
@@ -47,7 +46,7 @@ struct EnvParams {
     double* env_out;                   // optional [B][nb][L] smoothed envelope
     EnvRes* res_out;                   // [B][nb]
     int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
-    int aux_cmax, aux_cmin, aux_kept, aux_cand;  // byte offsets inside the auxiliary buffer (state[] sits at 0)
+    int aux_cmax, aux_cmin, aux_cpos, cand_cap;  // byte offsets inside the auxiliary buffer
     int stop_after;                    // development aid: leave the sequence after stage 1..5 (0 = run everything)
 };
 
@@ -56,7 +55,7 @@ struct EnvMisc {
     double ss_sm, ss_x, ss_d;                                          // round 2
     double mean_sm, mean_x, mean_d, std_sm, thr;
     double best_val;
-    int n_kept, undecided, best_idx, n_final, n_cand, pad;
+    int undecided, best_idx, n_final, n_cand;
 };
 
 inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
@@ -73,14 +72,13 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     // After the smoothing the buffer that held the raw envelope is reused: first as reduction scratch (7 quantities
     // x nt partials + fold area), then for the candidate states, the per-chunk extrema and the list of kept peaks.
     const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
-    int aux = ((L + 3) & ~3) * 4;                    // int state[L]
-    p.aux_cmax = aux; aux += ((nchunk + 1) & ~1) * 8;
-    p.aux_cmin = aux; aux += ((nchunk + 1) & ~1) * 8;
-    p.aux_kept = aux; aux += kEnvMaxKept * 4;
-    p.aux_cand = aux; aux += (L / 2 + 2) * 4;        // strict local maxima are at least two samples apart
+    int aux = 0;
+    p.aux_cmax = aux; aux += 5 * nchunk * 8;         // extrema of quarter chunks [4*nchunk], then of chunks [nchunk]
+    p.aux_cmin = aux; aux += 5 * nchunk * 8;
+    p.cand_cap = L / 2 + 2;                          // strict local maxima are at least two samples apart
+    p.aux_cpos = aux; aux += p.cand_cap * 7;         // int pos[cap]; byte state[cap], fk[cap], fu[cap]
     if (p.n > kEnvIterN * kEnvNT) return false;
-    return off <= 160 * 1024 && p.n * 16 >= (7 * kEnvNT + 7 * 64) * 8 && p.n * 16 >= aux &&
-           L / p.distance + 2 <= kEnvMaxKept;
+    return off <= 160 * 1024 && p.n * 16 >= (7 * kEnvNT + 7 * 64) * 8 && p.n * 16 >= aux;
 }
 
 inline void env_tables(const EnvParams& p, std::vector<cpx<double>>& roots, std::vector<cpx<double>>& wn,
@@ -125,7 +123,7 @@ ECHO_HD EnvPart1 ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsig
     for (int i = tid; i < p.plan.nroots; i += nt) r[i] = p.roots[i];
     if (tid == 0) {
         EnvMisc* m = env_misc(smem, p);
-        m->n_kept = 0; m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0;
+        m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0;
     }
     return a;
 }
@@ -201,16 +199,26 @@ ECHO_HD int reflect_idx(int i, int n) {
 
 // deterministic block reduction: K partials per thread at scratch[q*nt + tid]; op 0 sum, 1 max, 2 min
 ECHO_HD double red_op(int op, double a, double b) { return op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
+// On the device the per-thread partials are first folded inside each wavefront (red_wave, fixed-order butterfly), so
+// only lane 0 of a wavefront stores, and the fold reads one value per wavefront.
+ECHO_HD double red_identity(int op) { return op == 0 ? 0.0 : (op == 1 ? -INFINITY : INFINITY); }
+ECHO_HD double red_wave(int op, double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a = red_op(op, a, __shfl_xor(a, o));
+#endif
+    return a;
+}
 ECHO_HD void red_fold(int tid, int nt, double* scratch, int K, const int* ops) {
     if (tid >= 64) return;
     double* fold = scratch + K * nt;
     for (int q = 0; q < K; ++q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double a = tid < nt / 64 ? scratch[q * nt + tid * 64] : red_identity(ops[q]);
+        a = red_wave(ops[q], a);                          // every lane ends with the total
+#else
         double a = scratch[q * nt + tid];
         for (int t = tid + 64; t < nt; t += 64) a = red_op(ops[q], a, scratch[q * nt + t]);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the first wavefront finishes the fold with a fixed-order butterfly: every lane ends with the total
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) a = red_op(ops[q], a, __shfl_xor(a, o));
 #endif
         fold[q * 64 + tid] = a;
     }
@@ -231,11 +239,12 @@ ECHO_HD void ph_env_smooth(int tid, int nt, int blk, const EnvParams& p, unsigne
     const double* env = reinterpret_cast<const double*>(env_buf(smem, p, env_in));
     double* sm = reinterpret_cast<double*>(env_buf(smem, p, env_in ^ 1));
     const int h = p.smooth / 2;
+    const double inv_size = 1.0 / (double)p.smooth;
     for (int i = tid; i < p.L; i += nt) {
         double s = 0.0;
         if (i >= h && i + h < p.L) { for (int d = -h; d <= h; ++d) s += env[i + d]; }
         else { for (int d = -h; d <= h; ++d) s += env[reflect_idx(i + d, p.L)]; }
-        s = s / (double)p.smooth;
+        s = s * inv_size;
         sm[i] = s;
         if (p.env_out) p.env_out[(size_t)blk * p.L + i] = s;
         a.v[0] += s; a.v[1] = s > a.v[1] ? s : a.v[1]; a.v[2] = s < a.v[2] ? s : a.v[2];
@@ -244,7 +253,8 @@ ECHO_HD void ph_env_smooth(int tid, int nt, int blk, const EnvParams& p, unsigne
 }
 ECHO_HD void ph_env_part1_store(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf, const EnvPart1& a) {
     double* scratch = reinterpret_cast<double*>(env_buf(smem, p, scratch_buf));
-    for (int q = 0; q < 7; ++q) scratch[q * nt + tid] = a.v[q];
+    const int ops[7] = {0, 1, 2, 0, 0, 1, 0};
+    for (int q = 0; q < 7; ++q) scratch[q * nt + tid] = red_wave(ops[q], a.v[q]);
 }
 ECHO_HD void ph_env_part1_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
     const int ops[7] = {0, 1, 2, 0, 0, 1, 0};
@@ -275,7 +285,7 @@ ECHO_HD void ph_env_part2(int tid, int nt, int blk, const EnvParams& p, unsigned
         a += ds * ds;
         if (i + 1 < p.L) { const double dd = (sm[i + 1] - sm[i]) - mean_d; c += dd * dd; }
     }
-    scratch[tid] = a; scratch[nt + tid] = c;
+    scratch[tid] = red_wave(0, a); scratch[nt + tid] = red_wave(0, c);
 }
 ECHO_HD void ph_env_part2_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
     const int ops[2] = {0, 0};
@@ -297,95 +307,115 @@ ECHO_HD void ph_env_part2_final(int tid, int nt, const EnvParams& p, unsigned ch
 
 // -------------------------------------------------------------------------------- find_peaks
 // state[i]: 0 not a candidate, 1 undecided, 2 kept, 3 removed by the distance rule
-ECHO_HD int* env_state(unsigned char* smem, const EnvParams& p, int sm_buf) {
-    return reinterpret_cast<int*>(env_buf(smem, p, sm_buf ^ 1));
-}
+// Auxiliary buffer (the dead raw-envelope buffer): per-chunk extrema and the candidate slots.  A candidate is a local
+// maximum that passed the height filter; slot arrays: position, state (1 undecided, 2 kept, 3 removed) and the two
+// flags of a distance round (bytes: several threads may set a flag, none reads-modifies-writes it).
 ECHO_HD unsigned char* env_aux(unsigned char* smem, const EnvParams& p, int sm_buf) {
     return reinterpret_cast<unsigned char*>(env_buf(smem, p, sm_buf ^ 1));
 }
+struct EnvCand { int* pos; unsigned char* state; unsigned char* fk; unsigned char* fu; };
+ECHO_HD EnvCand env_cand(unsigned char* smem, const EnvParams& p, int sm_buf) {
+    unsigned char* a = env_aux(smem, p, sm_buf);
+    EnvCand c;
+    c.pos = reinterpret_cast<int*>(a + p.aux_cpos);
+    c.state = a + p.aux_cpos + 4 * p.cand_cap; c.fk = c.state + p.cand_cap; c.fu = c.fk + p.cand_cap;
+    return c;
+}
 ECHO_HD void ph_env_candidates(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    int* state = env_state(smem, p, sm_buf);
     double* cmax = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
     double* cmin = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
-    for (int i = tid; i < p.L; i += nt) state[i] = 0;
     const int nchunk = (p.L + kEnvChunk - 1) / kEnvChunk;
-    for (int c = tid; c < nchunk; c += nt) {
+    // four threads per chunk, 16 samples each; the chunk's extrema are folded by the prominence scan's reader
+    for (int t = tid; t < 4 * nchunk; t += nt) {
+        const int c = t >> 2, part = t & 3;
         double mx = -INFINITY, mn = INFINITY;
-        const int e = (c + 1) * kEnvChunk < p.L ? (c + 1) * kEnvChunk : p.L;
-        for (int i = c * kEnvChunk; i < e; ++i) { mx = sm[i] > mx ? sm[i] : mx; mn = sm[i] < mn ? sm[i] : mn; }
-        cmax[c] = mx; cmin[c] = mn;
+        const int b0 = c * kEnvChunk + part * (kEnvChunk / 4);
+        const int e = b0 + kEnvChunk / 4 < p.L ? b0 + kEnvChunk / 4 : p.L;
+        for (int i = b0; i < e; ++i) { mx = sm[i] > mx ? sm[i] : mx; mn = sm[i] < mn ? sm[i] : mn; }
+        cmax[t] = mx; cmin[t] = mn;
     }
 }
 // local maxima as scipy's _local_maxima_1d: x[i-1] < x[i], plateau x[i..j] equal, x[j+1] < x[i] -> (i + j) // 2
 ECHO_HD void ph_env_maxima(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    int* state = env_state(smem, p, sm_buf);
-    int* cand = reinterpret_cast<int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
+    const EnvCand c = env_cand(smem, p, sm_buf);
     EnvMisc* m = env_misc(smem, p);
-    for (int i = tid + 1; i < p.L - 1; i += nt) {
-        if (!(sm[i - 1] < sm[i])) continue;
-        int j = i;
-        while (j + 1 < p.L && sm[j + 1] == sm[i]) ++j;
-        if (j + 1 >= p.L || !(sm[j + 1] < sm[i])) continue;
-        const int mid = (i + j) / 2;
-        if (sm[mid] >= m->thr) {                         // height filter: thr <= peak height
-            state[mid] = 1;
-            cand[env_lds_add(&m->n_cand, 1)] = mid;
+    const double thr = m->thr;
+    {
+        double* cmax = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
+        double* cmin = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
+        const int nchunk = (p.L + kEnvChunk - 1) / kEnvChunk;
+        for (int ch = tid; ch < nchunk; ch += nt) {
+            double mx = cmax[4 * ch], mn = cmin[4 * ch];
+            for (int q = 1; q < 4; ++q) {
+                mx = cmax[4 * ch + q] > mx ? cmax[4 * ch + q] : mx;
+                mn = cmin[4 * ch + q] < mn ? cmin[4 * ch + q] : mn;
+            }
+            cmax[4 * nchunk + ch] = mx; cmin[4 * nchunk + ch] = mn;
         }
     }
+    for (int i = tid + 1; i < p.L - 1; i += nt) {
+        const double v = sm[i];
+        if (!(v >= thr) || !(sm[i - 1] < v)) continue;   // height filter first: it rejects almost every sample
+        int j = i;
+        while (j + 1 < p.L && sm[j + 1] == v) ++j;
+        if (j + 1 >= p.L || !(sm[j + 1] < v)) continue;
+        const int slot = env_lds_add(&m->n_cand, 1);
+        c.pos[slot] = (i + j) / 2; c.state[slot] = 1; c.fk[slot] = 0; c.fu[slot] = 0;
+    }
 }
-ECHO_HD bool env_higher(const double* sm, int j, int i) { return sm[j] > sm[i] || (sm[j] == sm[i] && j > i); }
-// one round of the distance rule over the candidate list: a candidate is removed when a kept candidate of higher
-// priority lies within distance-1 samples, kept when every higher-priority candidate in that range is already removed
-ECHO_HD void ph_env_distance_round(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+// Distance rule (scipy _select_by_peak_distance: highest first, a kept peak removes every peak within distance-1
+// samples) as a fixpoint: a candidate is removed when a kept candidate of higher priority lies in that range, kept
+// when every higher-priority candidate in range is already removed.  One round = all (candidate, other) pairs in
+// parallel setting the two flags, then one update per candidate.
+ECHO_HD bool env_higher(double vj, int pj, double vi, int pi) { return vj > vi || (vj == vi && pj > pi); }
+ECHO_HD void ph_env_distance_pairs(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    int* state = env_state(smem, p, sm_buf);
-    const int* cand = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
+    const EnvCand c = env_cand(smem, p, sm_buf);
+    const int nc = env_misc(smem, p)->n_cand;
+    for (int e = tid; e < nc * nc; e += nt) {
+        const int i = e / nc, u = e - i * nc;
+        if (i == u || c.state[i] != 1) continue;
+        const int su = c.state[u];
+        if (su == 3) continue;
+        const int d = c.pos[u] > c.pos[i] ? c.pos[u] - c.pos[i] : c.pos[i] - c.pos[u];
+        if (d >= p.distance || !env_higher(sm[c.pos[u]], c.pos[u], sm[c.pos[i]], c.pos[i])) continue;
+        if (su == 2) c.fk[i] = 1; else c.fu[i] = 1;
+    }
+}
+ECHO_HD void ph_env_distance_update(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    const EnvCand c = env_cand(smem, p, sm_buf);
     EnvMisc* m = env_misc(smem, p);
     const int nc = m->n_cand;
     for (int t = tid; t < nc; t += nt) {
-        const int i = cand[t];
-        if (state[i] != 1) continue;
-        bool removed = false, wait = false;
-        for (int u = 0; u < nc; ++u) {
-            const int j = cand[u];
-            const int d = j > i ? j - i : i - j;
-            if (d == 0 || d >= p.distance) continue;
-            const int sj = state[j];
-            if (sj == 3 || !env_higher(sm, j, i)) continue;
-            if (sj == 2) { removed = true; break; }
-            wait = true;
-        }
-        if (removed) state[i] = 3;
-        else if (!wait) state[i] = 2;
-        else env_lds_add(&m->undecided, 1);
+        if (c.state[t] != 1) continue;
+        if (c.fk[t]) c.state[t] = 3;
+        else if (!c.fu[t]) c.state[t] = 2;
+        else m->undecided = 1;
+        c.fk[t] = 0; c.fu[t] = 0;
     }
 }
-ECHO_HD void ph_env_collect(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
-    const int* state = env_state(smem, p, sm_buf);
-    const int* cand = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_cand);
-    int* kept = reinterpret_cast<int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
-    EnvMisc* m = env_misc(smem, p);
-    for (int t = tid; t < m->n_cand; t += nt)
-        if (state[cand[t]] == 2) {
-            const int slot = env_lds_add(&m->n_kept, 1);
-            if (slot < kEnvMaxKept) kept[slot] = cand[t];
-        }
-}
-// prominence of each kept peak (scipy _peak_prominences, wlen = None) with chunk-wise skipping; peaks below the
-// required prominence (std of the envelope) are dropped; the best surviving peak at or beyond min_delay is chosen
+// prominence of each kept peak (scipy _peak_prominences, wlen = None) with chunk-wise skipping (quarter-chunk
+// extrema); peaks below the required prominence (std of the envelope) are dropped
 ECHO_HD double env_side_min(const double* sm, const double* cmax, const double* cmin, int L, int peak, int dir) {
+    constexpr int Q = kEnvChunk / 4;
+    const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
     const double h = sm[peak];
     double mn = h;
     int i = peak + dir;
     while (i >= 0 && i < L) {
-        const int c = i / kEnvChunk;
-        const int cb = c * kEnvChunk, ce = (c + 1) * kEnvChunk < L ? (c + 1) * kEnvChunk : L;
-        const bool whole = dir < 0 ? (i == ce - 1) : (i == cb);
-        if (whole && cmax[c] <= h) {                     // the whole chunk is at or below the peak: take its minimum
-            mn = cmin[c] < mn ? cmin[c] : mn;
+        // whole chunk (64 samples), then whole quarter chunk (16), at or below the peak: take its minimum and jump
+        const int c = i / kEnvChunk, cb = c * kEnvChunk, ce = cb + kEnvChunk;
+        if (ce <= L && (dir < 0 ? i == ce - 1 : i == cb) && cmax[4 * nchunk + c] <= h) {
+            mn = cmin[4 * nchunk + c] < mn ? cmin[4 * nchunk + c] : mn;
             i = dir < 0 ? cb - 1 : ce;
+            continue;
+        }
+        const int q = i / Q, qb = q * Q, qe = qb + Q;
+        if (qe <= L && (dir < 0 ? i == qe - 1 : i == qb) && cmax[q] <= h) {
+            mn = cmin[q] < mn ? cmin[q] : mn;
+            i = dir < 0 ? qb - 1 : qe;
             continue;
         }
         if (sm[i] > h) break;
@@ -398,17 +428,16 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     const double* cmax = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
     const double* cmin = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
-    int* state = env_state(smem, p, sm_buf);
-    const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
+    const EnvCand c = env_cand(smem, p, sm_buf);
     EnvMisc* m = env_misc(smem, p);
-    const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
-    for (int t = tid; t < nk; t += nt) {
-        const int i = kept[t];
+    const int nc = m->n_cand;
+    for (int t = tid; t < nc; t += nt) {
+        if (c.state[t] != 2) continue;
+        const int i = c.pos[t];
         const double lmin = env_side_min(sm, cmax, cmin, p.L, i, -1);
         const double rmin = env_side_min(sm, cmax, cmin, p.L, i, +1);
         const double base = lmin > rmin ? lmin : rmin;
-        const double prom = sm[i] - base;
-        if (!(prom >= m->std_sm)) state[i] = 3;
+        if (!(sm[i] - base >= m->std_sm)) c.state[t] = 3;
         else env_lds_add(&m->n_final, 1);
     }
 }
@@ -416,18 +445,17 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
 ECHO_HD void ph_env_select(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     if (tid != 0) return;
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    const int* state = env_state(smem, p, sm_buf);
-    const int* kept = reinterpret_cast<const int*>(env_aux(smem, p, sm_buf) + p.aux_kept);
+    const EnvCand c = env_cand(smem, p, sm_buf);
     EnvMisc* m = env_misc(smem, p);
-    const int nk = m->n_kept < kEnvMaxKept ? m->n_kept : kEnvMaxKept;
-    int best = -1;
-    for (int t = 0; t < nk; ++t) {
-        const int i = kept[t];
-        if (state[i] != 2 || i < p.min_delay) continue;
-        if (best < 0 || sm[i] > sm[best] || (sm[i] == sm[best] && i < best)) best = i;
+    const int nc = m->n_cand;
+    int best = -1; double bv = 0.0;
+    for (int t = 0; t < nc; ++t) {
+        if (c.state[t] != 2 || c.pos[t] < p.min_delay) continue;
+        const double v = sm[c.pos[t]];
+        if (best < 0 || v > bv || (v == bv && c.pos[t] < best)) { best = c.pos[t]; bv = v; }
     }
     m->best_idx = best;
-    m->best_val = best >= 0 ? sm[best] : 0.0;
+    m->best_val = best >= 0 ? bv : 0.0;
 }
 ECHO_HD double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* smem) {
@@ -467,7 +495,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
             cur_ ^= 1;                                                                                       \
             if ((p).stop_after == 7 + ps_) break;                                                            \
         }                                                                                                    \
-        if ((p).stop_after >= 7) break;                                                                                                    \
+        if ((p).stop_after >= 7 && (p).stop_after <= 9) break;                                                                                                    \
         if ((p).stop_after == 1) break;                                                                      \
         PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
         for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
@@ -479,23 +507,28 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         cur_ ^= 1;                               /* cur_: envelope */                                        \
         PHASE(ph_env_smooth(tid, nt, blk, p, smem, cur_, PART1_REF)) SYNC                                   \
         const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \
+        if ((p).stop_after == 10) break;                                                                     \
         PHASE(ph_env_part1_store(tid, nt, p, smem, scr_, PART1_REF)) SYNC                                    \
         PHASE(ph_env_part1_fold(tid, nt, p, smem, scr_)) SYNC                                                \
         PHASE(ph_env_part1_final(tid, nt, p, smem, scr_)) SYNC                                               \
+        if ((p).stop_after == 11) break;                                                                     \
         PHASE(ph_env_part2(tid, nt, blk, p, smem, sm_)) SYNC                                                 \
         PHASE(ph_env_part2_fold(tid, nt, p, smem, scr_)) SYNC                                                \
         PHASE(ph_env_part2_final(tid, nt, p, smem, scr_)) SYNC                                               \
         if ((p).stop_after == 3) break;                                                                      \
         PHASE(ph_env_candidates(tid, nt, p, smem, sm_)) SYNC                                                 \
+        if ((p).stop_after == 12) break;                                                                     \
         PHASE(ph_env_maxima(tid, nt, p, smem, sm_)) SYNC                                                     \
+        if ((p).stop_after == 13) break;                                                                     \
         for (int round_ = 0; round_ < (p).L; ++round_) {                                                     \
-            PHASE(if (tid == 0) env_misc(smem, p)->undecided = 0) SYNC                                       \
-            PHASE(ph_env_distance_round(tid, nt, p, smem, sm_)) SYNC                                         \
+            PHASE(ph_env_distance_pairs(tid, nt, p, smem, sm_)) SYNC                                         \
+            PHASE(ph_env_distance_update(tid, nt, p, smem, sm_)) SYNC                                        \
             const int left_ = env_misc(smem, p)->undecided;                                                  \
             SYNC                                                                                             \
             if (left_ == 0) break;                                                                           \
+            PHASE(if (tid == 0) env_misc(smem, p)->undecided = 0)                                            \
         }                                                                                                    \
-        PHASE(ph_env_collect(tid, nt, p, smem, sm_)) SYNC                                                         \
+        if ((p).stop_after == 4) break;                                                                      \
         PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
         if ((p).stop_after == 5) break;                                                                      \
         PHASE(ph_env_select(tid, nt, p, smem, sm_)) SYNC                                                     \

@@ -24,7 +24,8 @@ struct GfftPlan {
     int radix[kGfftMaxPass];     // largest first: the first pass needs no twiddles
     int lp[kGfftMaxPass];        // product of the radices of the earlier passes
     int root_off[kGfftMaxPass];  // offset of the pass's r roots exp(-2*pi*i*t/r) in the roots table
-    int pairs[kGfftMaxPass];     // conjugate output pairs per wavefront item (1..4), chosen for nt threads
+    int pairs[kGfftMaxPass];     // conjugate output pairs per work item (1..3), chosen for nt threads
+    int per_lane[kGfftMaxPass];  // 1: items are (pair block, butterfly) per lane; 0: (pair block, 64 butterflies) per wavefront
     int nroots;
 };
 
@@ -52,12 +53,24 @@ inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512) {
         // pairs per wavefront item: fewest rounds over the nt/64 wavefronts, weighted by the work per item
         const int npair = out[i] / 2 + 1, nchunk = (n / out[i] + 63) / 64, nw = nt / 64 > 0 ? nt / 64 : 1;
         int best = 1, best_cost = 1 << 30;
-        for (int P = 1; P <= 4; ++P) {
+        for (int P = 1; P <= 3; ++P) {
             const int items = ((npair + P - 1) / P) * nchunk;
             const int cost = ((items + nw - 1) / nw) * (P + 1);      // + 1: the input read and loop overhead
             if (cost < best_cost) { best_cost = cost; best = P; }
         }
-        pl.pairs[i] = best;
+        pl.pairs[i] = best; pl.per_lane[i] = 0;
+        // few butterflies per pass (n/r well below a multiple of 64) leave lanes idle in the wavefront mapping:
+        // then every lane takes its own (pair block, butterfly) and keeps its own root indices
+        const int cols = n / out[i];
+        if (cols * 4 < nchunk * 64 * 3) {
+            best = 1; best_cost = 1 << 30;
+            for (int P = 1; P <= 3; ++P) {
+                const int items = ((npair + P - 1) / P) * cols;
+                const int cost = ((items + nt - 1) / nt) * (2 * P + 1);   // index arithmetic per pair is vector work here
+                if (cost < best_cost) { best_cost = cost; best = P; }
+            }
+            pl.pairs[i] = best; pl.per_lane[i] = 1;
+        }
     }
     pl.npass = no;
     return true;
@@ -197,14 +210,114 @@ ECHO_HD void gfft_pass_p(int tid, int nt, const GfftPlan& pl, int ps, const cpx<
     }
 }
 
+// Per-lane mapping of the same pass: work item = (pair block, butterfly), consecutive lanes take consecutive
+// butterflies and run into the next pair block, so all lanes are busy when a pass has few butterflies.  Root
+// indices differ between lanes (vector arithmetic, LDS gathers of a few distinct addresses).
+template <class T, int P>
+ECHO_HD void gfft_pass_lane(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out,
+                            const cpx<T>* roots, const cpx<T>* wn, bool inv) {
+    const int r = pl.radix[ps], Lp = pl.lp[ps], m = pl.n / (Lp * r);
+    const int npair = r / 2 + 1, npb = (npair + P - 1) / P, cols = Lp * m, items = npb * cols;
+    const bool last = ps + 1 >= pl.npass;
+    const int m2 = last ? 1 : pl.n / (pl.lp[ps + 1] * pl.radix[ps + 1]);
+    for (int it = tid; it < items; it += nt) {
+        const int pb = it / cols, c = it - pb * cols;
+        const int k = c / m, j = c - k * m;
+        const int t0 = pb * P;
+        unsigned idx[P], step[P];
+        T A[P], B[P], C[P], D[P];
+        cpx<T> wa[P], wb[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            step[u] = t0 + u < npair ? (unsigned)(t0 + u) : 0u;
+            A[u] = B[u] = C[u] = D[u] = (T)0;
+            wa[u] = roots[0];
+            wb[u] = roots[step[u]];
+            idx[u] = 2 * step[u];
+            idx[u] = idx[u] < idx[u] - (unsigned)r ? idx[u] : idx[u] - (unsigned)r;   // min(i, i - r) as unsigned = i mod r
+        }
+        const int s2m2 = last ? 0 : (j / m2) * m2;
+        cpx<T> tw[2 * P];
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = (int)step[u], qe = (e && q) ? r - q : q;
+                tw[2 * u + e] = last ? cpx<T>{(T)1, (T)0} : wn[s2m2 * (k + Lp * qe)];
+            }
+        const cpx<T>* src = in + k * (m * r) + j;
+        cpx<T> va = src[0], vb = src[r > 1 ? m : 0];
+        int s = 0;
+        for (; s + 1 < r; s += 2) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(va.x, wa[u].x, A[u]); B[u] = gf_fma(va.y, wa[u].y, B[u]);
+                C[u] = gf_fma(va.x, wa[u].y, C[u]); D[u] = gf_fma(va.y, wa[u].x, D[u]);
+            }
+            va = src[m * (s + 2 < r ? s + 2 : r - 1)];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                wa[u] = roots[idx[u]];
+                idx[u] += step[u];
+                idx[u] = idx[u] < idx[u] - (unsigned)r ? idx[u] : idx[u] - (unsigned)r;
+            }
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(vb.x, wb[u].x, A[u]); B[u] = gf_fma(vb.y, wb[u].y, B[u]);
+                C[u] = gf_fma(vb.x, wb[u].y, C[u]); D[u] = gf_fma(vb.y, wb[u].x, D[u]);
+            }
+            vb = src[m * (s + 3 < r ? s + 3 : r - 1)];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                wb[u] = roots[idx[u]];
+                idx[u] += step[u];
+                idx[u] = idx[u] < idx[u] - (unsigned)r ? idx[u] : idx[u] - (unsigned)r;
+            }
+        }
+        if (s < r) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                A[u] = gf_fma(va.x, wa[u].x, A[u]); B[u] = gf_fma(va.y, wa[u].y, B[u]);
+                C[u] = gf_fma(va.x, wa[u].y, C[u]); D[u] = gf_fma(va.y, wa[u].x, D[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int q = t0 + u;
+            if (q >= npair) continue;
+            cpx<T> o[2];
+            o[0].x = A[u] - B[u]; o[0].y = C[u] + D[u];
+            o[1].x = A[u] + B[u]; o[1].y = D[u] - C[u];
+            const int nout = (q == 0 || r - q == q) ? 1 : 2;
+            for (int e = 0; e < nout; ++e) {
+                cpx<T> a = o[inv ? 1 - e : e];
+                if (!last) {
+                    const cpx<T> t = tw[2 * u + e];
+                    const T wy = inv ? -t.y : t.y;
+                    const T re = a.x * t.x - a.y * wy, im = a.x * wy + a.y * t.x;
+                    a.x = re; a.y = im;
+                }
+                out[(k + Lp * (e ? r - q : q)) * m + j] = a;
+            }
+        }
+    }
+}
+
 template <class T>
 ECHO_HD void gfft_pass(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
                        const cpx<T>* wn, bool inv) {
+    if (pl.per_lane[ps]) {
+        switch (pl.pairs[ps]) {
+            case 1: gfft_pass_lane<T, 1>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+            case 2: gfft_pass_lane<T, 2>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+            default: gfft_pass_lane<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+        }
+        return;
+    }
     switch (pl.pairs[ps]) {
         case 1: gfft_pass_p<T, 1>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
         case 2: gfft_pass_p<T, 2>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
-        case 3: gfft_pass_p<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
-        default: gfft_pass_p<T, 4>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
+        default: gfft_pass_p<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); break;
     }
 }
 
