@@ -27,6 +27,21 @@ struct EchoHandle {
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
     float2* d_uk = nullptr;
     cpx<float> *d_lroots = nullptr, *d_lwn = nullptr, *d_luk = nullptr;   // long path: spectrum FFT tables
+    // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
+    hipStream_t pf_stream = nullptr;
+    hipEvent_t pf_ready[2] = {nullptr, nullptr}, pf_consumed[2] = {nullptr, nullptr}, pf_t0 = nullptr, pf_t1 = nullptr;
+    bool pf_consumed_set[2] = {false, false};
+    hipEvent_t chain_end[2] = {nullptr, nullptr};   // end of the last two chain calls (alternating)
+    int chain_gen = 0; bool chain_end_set[2] = {false, false};
+    int pf_gate = 1;                                // 1: a prefetch starts when the chain call before the latest one has
+                                                    // finished, i.e. it runs under the latest call's band kernel; 0: as soon as
+                                                    // its buffer is free (ECHO_PF_GATE overrides, for experiments)
+    double* pf_y[2] = {nullptr, nullptr};
+    double* pf_fwd = nullptr;
+    int pf_cap = 0, pf_next = 0;
+    const float* pf_rx = nullptr;          // outstanding prefetch: input, size, slot
+    int pf_B = 0, pf_slot = 0;
+    bool pf_valid = false, pf_timed = false;
     bool long_path = false;                // frame too long for one workgroup, or the MAD detector: tiled kernels
     LongParams lbase;
     // device constant tables
@@ -111,9 +126,9 @@ int ensure_full_scratch(EchoHandle* h, int frames) {
 
 // Zero-phase IIR for B frames.  Small batches cannot fill the chip with one lane per (frame, band) (a wave is a
 // serial stream of ~370k instructions), so they run the quad-lane kernel: 4x the waves, each 1.8x shorter.
-int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s) {
+int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, double* fwd = nullptr) {
     IirParams p;
-    p.rx = rx; p.y = y; p.fwd = h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
+    p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands;
     p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     const long lane_waves = (long)p.nb * ((B + 63) / 64);
@@ -121,6 +136,33 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s) {
     if (quad) { p.ntiles = (B + 15) / 16; return launch_iir_quad(p, h->cfg.iir_ncoef, s); }
     p.ntiles = (B + 63) / 64;
     return launch_iir(p, h->cfg.iir_ncoef, h->bodd0, s);
+}
+
+int ensure_prefetch(EchoHandle* h, int frames) {
+    if (!h->pf_stream) {
+        if (hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&h->pf_ready[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->pf_consumed[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+        if (hipEventCreate(&h->pf_t0) != hipSuccess || hipEventCreate(&h->pf_t1) != hipSuccess) return ECHO_ERR_HIP;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&h->chain_end[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+        if (const char* g = std::getenv("ECHO_PF_GATE")) h->pf_gate = std::atoi(g);
+    }
+    if (frames <= h->pf_cap) return ECHO_OK;
+    if (hipStreamSynchronize(h->pf_stream) != hipSuccess) return ECHO_ERR_HIP;     // nothing may still use the old buffers
+    (void)hipFree(h->pf_y[0]); (void)hipFree(h->pf_y[1]); (void)hipFree(h->pf_fwd);
+    h->pf_y[0] = h->pf_y[1] = h->pf_fwd = nullptr; h->pf_cap = 0; h->pf_valid = false;
+    const EchoConfig& c = h->cfg;
+    const size_t ntiles = (size_t)(frames + 63) / 64;
+    const size_t fwd_n = (size_t)c.n_bands * ntiles * (size_t)(c.n_rx + 6 * c.iir_ncoef) * 64;
+    const size_t y_n = (size_t)frames * c.n_bands * c.n_rx;
+    if (hipMalloc(reinterpret_cast<void**>(&h->pf_fwd), fwd_n * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->pf_y[0]), y_n * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->pf_y[1]), y_n * sizeof(double)) != hipSuccess)
+        return ECHO_ERR_NOMEM;
+    h->pf_cap = frames;
+    return ECHO_OK;
 }
 
 FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, double* fused, uint8_t* vany, int B) {
@@ -253,6 +295,14 @@ void echo_destroy(EchoHandle* h) {
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->pf_stream) {
+        (void)hipStreamSynchronize(h->pf_stream);
+        (void)hipStreamDestroy(h->pf_stream);
+        hipEvent_t evs[] = {h->pf_ready[0], h->pf_ready[1], h->pf_consumed[0], h->pf_consumed[1], h->pf_t0, h->pf_t1,
+                            h->chain_end[0], h->chain_end[1]};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
+    (void)hipFree(h->pf_y[0]); (void)hipFree(h->pf_y[1]); (void)hipFree(h->pf_fwd);
     delete h;
 }
 
@@ -489,8 +539,17 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         const bool prof = h->prof && f0 == 0 && h->prof_used < h->prof_slots;
         hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
-        rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
-        if (rc) return rc;
+        // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
+        const bool pre = f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B && !h->long_path;
+        const double* y_in = h->d_y;
+        if (f0 == 0) h->pf_valid = false;                  // consumed or discarded
+        if (pre) {
+            if (hipStreamWaitEvent(s, h->pf_ready[h->pf_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
+            y_in = h->pf_y[h->pf_slot];
+        } else {
+            rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
+            if (rc) return rc;
+        }
         if (prof) (void)hipEventRecord(ev[1], s);
         if (h->long_path) {
             LongParams q = h->lbase;
@@ -513,16 +572,20 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 0;
-            p.d_in = h->d_y; p.res_out = h->d_res; p.corr_io = h->d_corr; p.bandf_out = h->d_bandf;
+            p.d_in = y_in; p.res_out = h->d_res; p.corr_io = h->d_corr; p.bandf_out = h->d_bandf;
             rc = launch_band(p, n, s);
             if (rc) return rc;
         } else {
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
-            p.d_in = h->d_y; p.res_out = h->d_res;
+            p.d_in = y_in; p.res_out = h->d_res;
             p.bandf_out = spec_db ? h->d_bandf : nullptr;
             rc = launch_band(p, n, s);
             if (rc) return rc;
+        }
+        if (pre) {                                         // the band kernel was the last reader of the prefetched IIR output
+            if (hipEventRecord(h->pf_consumed[h->pf_slot], s) != hipSuccess) return ECHO_ERR_HIP;
+            h->pf_consumed_set[h->pf_slot] = true;
         }
         if (prof) (void)hipEventRecord(ev[2], s);
         if (h->long_path) {
@@ -558,6 +621,11 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         }
         if (prof) { (void)hipEventRecord(ev[4], s); ++h->prof_used; }
     }
+    if (h->pf_stream && h->pf_gate) {
+        h->chain_gen ^= 1;
+        (void)hipEventRecord(h->chain_end[h->chain_gen], s);
+        h->chain_end_set[h->chain_gen] = true;
+    }
     return ECHO_OK;
 }
 
@@ -569,6 +637,37 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality, double* kalman_x,
                     double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
     return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
+}
+
+int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
+    if (!h || !rx || B < 1) return ECHO_ERR_INVALID;
+    if (h->long_path || B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
+    int rc = ensure_prefetch(h, B);
+    if (rc) return rc;
+    const int slot = h->pf_next;
+    // the previous result in this slot must have been read (band kernel of the call that consumed it)
+    if (h->pf_consumed_set[slot]) {
+        if (hipStreamWaitEvent(h->pf_stream, h->pf_consumed[slot], 0) != hipSuccess) return ECHO_ERR_HIP;
+        h->pf_consumed_set[slot] = false;
+    }
+    if (h->pf_gate && h->chain_end_set[h->chain_gen ^ 1])
+        (void)hipStreamWaitEvent(h->pf_stream, h->chain_end[h->chain_gen ^ 1], 0);
+    (void)hipEventRecord(h->pf_t0, h->pf_stream);
+    rc = run_iir(h, rx, h->pf_y[slot], B, h->pf_stream, h->pf_fwd);
+    if (rc) return rc;
+    (void)hipEventRecord(h->pf_t1, h->pf_stream);
+    h->pf_timed = true;
+    if (hipEventRecord(h->pf_ready[slot], h->pf_stream) != hipSuccess) return ECHO_ERR_HIP;
+    h->pf_rx = rx; h->pf_B = B; h->pf_slot = slot; h->pf_valid = true;
+    h->pf_next = slot ^ 1;
+    return ECHO_OK;
+}
+
+int echo_prefetch_ms(EchoHandle* h, float* iir_ms) {
+    if (!h || !iir_ms || !h->pf_timed) return ECHO_ERR_INVALID;
+    if (hipEventSynchronize(h->pf_t1) != hipSuccess || hipEventElapsedTime(iir_ms, h->pf_t0, h->pf_t1) != hipSuccess)
+        return ECHO_ERR_HIP;
+    return ECHO_OK;
 }
 
 struct EchoGraph {
@@ -585,6 +684,7 @@ int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool prof = h->prof;
     h->prof = false;                        // timing events are not part of the recorded work
+    h->pf_valid = false;                    // nor is a pending prefetch: the graph always runs its own IIR
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->prof = prof; return ECHO_ERR_HIP; }
     rc = echo_chain(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream);
     EchoGraph* g = new (std::nothrow) EchoGraph();

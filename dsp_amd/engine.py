@@ -193,6 +193,18 @@ class EchoEngine:
                                            B, S, self._stream()), "echo_chain")
         return out, spec
 
+    def chain_prefetch(self, rx: torch.Tensor):
+        """Start the IIR of the batch the next ``chain`` call will get (same tensor), on the engine's own stream, so it
+        overlaps the current batch's kernels.  ``rx`` must be a complete, contiguous float32 device tensor [B, N]
+        that stays unchanged until that call."""
+        assert rx.is_cuda and rx.dtype == torch.float32 and rx.is_contiguous() and rx.shape[1] == self.cfg.n_rx
+        _lib.check(self.lib.echo_chain_prefetch(self._h, _ptr(rx), rx.shape[0]), "echo_chain_prefetch")
+
+    def prefetch_ms(self) -> float:
+        v = C.c_float()
+        _lib.check(self.lib.echo_prefetch_ms(self._h, C.byref(v)), "echo_prefetch_ms")
+        return v.value
+
     def capture_chain(self, rx: torch.Tensor, kalman: "BatchedKalman", want_spectra: bool = False) -> "ChainGraph":
         """Streaming mode: records one chain call over the device buffer ``rx`` [S, N] (one frame per stream, i.e.
         one tick of realtime_sonar.py's loop) into a HIP graph.  Per tick, copy the new frames into ``rx`` and call

@@ -165,6 +165,17 @@ int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
 
+/* Pipelining across batches (no counterpart in the reference).  The zero-phase IIR is a sequential recurrence that
+ * leaves most of the chip idle while the other kernels of the chain are arithmetic-bound, so the IIR of the next
+ * batch can run under the kernels of the current one.  echo_chain_prefetch starts it on a stream owned by the
+ * handle; the next echo_chain / echo_chain_full call with the same rx and B uses the result instead of filtering
+ * again (any other chain call discards it).  The caller guarantees that rx[B][N] is complete in device memory at the
+ * time of the call -- the prefetch is not ordered after work on a caller stream -- and unchanged until that chain
+ * call has been issued.  B must fit one internal pass (16384 frames).  echo_prefetch_ms: device time of the most
+ * recent prefetched IIR. */
+int echo_chain_prefetch(EchoHandle* h, const float* rx, int B);
+int echo_prefetch_ms(EchoHandle* h, float* iir_ms);
+
 /* Streaming mode (realtime_sonar.py:300-350: one frame per stream per tick, Kalman state carried between ticks):
  * echo_graph_create records one echo_chain call with exactly these arguments into a HIP graph (stream capture on
  * `stream`, which must not be the null stream; nothing executes during the capture).  echo_graph_launch replays it:
