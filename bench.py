@@ -220,6 +220,18 @@ def main():
                          "note": "VALU/LDS-bound chain (~13 MFLOP/frame f64+f32): HBM fraction is low by construction"},
             "kernel_ms": kms,
         }
+        if args.workload != "original" and args.mode == "named":
+            # what bounds this kernel: multiply-adds of the FIR and the matched filter against the vector peaks
+            # (float64 78.6 TFLOP/s, float32 157.3 TFLOP/s; the chain splits each by what the detector reads)
+            nexact = cfg.half + cfg.min_delay - (cfg.n_chirp - 1)
+            f64 = cfg.FIR_TAPS * (cfg.n_rx - nexact) + cfg.n_chirp * (cfg.n_corr - cfg.half - cfg.min_delay)
+            f32 = cfg.FIR_TAPS * nexact + cfg.n_chirp * cfg.half
+            per_launch = launch_frames * cfg.n_bands
+            t_peak = per_launch * 2.0 * (f64 / 78.6e12 + f32 / 157.3e12)
+            out["valu"] = {"kernel": "band_kernel", "f64_fma_per_frame_band": f64, "f32_fma_per_frame_band": f32,
+                           "seconds_at_vector_peak": t_peak, "frac_of_vector_peak": t_peak / band_s,
+                           "note": "supplementary: the band kernel is bound by vector instruction issue, not by HBM"
+                                   + ("; its duration here includes the co-running prefetched IIR" if pipeline else "")}
         if world == 1 and not args.no_cpu_baseline and args.workload == "optimized":
             out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds, args.cpu_workers)
         print(json.dumps(out), flush=True)
