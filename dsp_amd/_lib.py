@@ -59,7 +59,7 @@ def load():
     lib.echo_mag2db.argtypes = [P, P, C.c_size_t, P]
     lib.echo_correlate.argtypes = [P, P, P, I, P]
     lib.echo_first_strong_peak.argtypes = [P, P, P, P, P, I, P]
-    lib.echo_envelope_detection.argtypes = [P, P, P, P, P, P, P, I, P]
+    lib.echo_envelope_detection.argtypes = [P, P, P, P, P, P, P, P, I, P]
     lib.echo_argmax.argtypes = [P, P, I, I, P]
     lib.echo_confidence_fuse.argtypes = [P, P, P, P, P, I, P]
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]

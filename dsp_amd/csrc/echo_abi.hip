@@ -457,7 +457,7 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
 }
 
 int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
-                            double* quality, int32_t* n_peaks, int B, void* stream) {
+                            double* quality, int32_t* n_peaks, int32_t* peaks, int B, void* stream) {
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !corr || B < 0) return ECHO_ERR_INVALID;
     if (!h->has_env) return ECHO_ERR_UNSUPPORTED;
@@ -470,6 +470,7 @@ int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope,
         EnvParams q = h->ebase;
         const size_t o = (size_t)f0 * nb;
         q.corr = corr + o * q.L; q.env_out = envelope ? envelope + o * q.L : nullptr; q.res_out = h->d_env;
+        q.peaks_out = peaks ? peaks + o * kEnvMaxPeaks : nullptr;
         rc = launch_corr_env(q, n, s);
         if (rc) return rc;
         rc = launch_unpack_env(h->d_env, peak_idx ? peak_idx + o : nullptr, snr_db ? snr_db + o : nullptr,
@@ -597,7 +598,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_spec_hilbert(q, n, s);
             if (rc) return rc;
             EnvParams e = h->ebase;
-            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = h->d_env;
+            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = h->d_env; e.peaks_out = nullptr;
             rc = launch_corr_env(e, n, s);
             if (rc) return rc;
         } else if (spec_db) {

@@ -26,6 +26,7 @@ ECHO_HD int env_lds_add(int* p, int v) {
 constexpr int kEnvNT = 512;
 constexpr int kEnvIterN = 5;           // n <= kEnvIterN * nt: per-thread trip count of the loops over n, unrolled so
                                        // that the global loads of all trips are in flight together
+constexpr int kEnvMaxPeaks = 64;       // find_peaks with distance L // 50 returns at most 51 peaks
 constexpr int kEnvChunk = 64;          // prominence scan: per-chunk max/min
 
 struct EnvRes {                        // per (frame, band)
@@ -45,6 +46,7 @@ struct EnvParams {
     const double* corr;                // [B][nb][L] raw correlation
     double* env_out;                   // optional [B][nb][L] smoothed envelope
     EnvRes* res_out;                   // [B][nb]
+    int32_t* peaks_out;                // optional [B][nb][kEnvMaxPeaks]: corr_peaks in ascending order, -1 padded
     int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
     int aux_cmax, aux_cmin, aux_cpos, cand_cap;  // byte offsets inside the auxiliary buffer
     int stop_after;                    // development aid: leave the sequence after stage 1..5 (0 = run everything)
@@ -457,6 +459,20 @@ ECHO_HD void ph_env_select(int tid, int nt, const EnvParams& p, unsigned char* s
     m->best_idx = best;
     m->best_val = best >= 0 ? bv : 0.0;
 }
+// corr_peaks: the surviving candidates in ascending order (rank by counting; they are few)
+ECHO_HD void ph_env_peaks_out(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    if (!p.peaks_out) return;
+    const EnvCand c = env_cand(smem, p, sm_buf);
+    const int nc = env_misc(smem, p)->n_cand;
+    int32_t* dst = p.peaks_out + (size_t)blk * kEnvMaxPeaks;
+    for (int t = tid; t < kEnvMaxPeaks; t += nt) dst[t] = -1;
+    for (int t = tid; t < nc; t += nt) {
+        if (c.state[t] != 2) continue;
+        int rank = 0;
+        for (int u = 0; u < nc; ++u) rank += (c.state[u] == 2 && c.pos[u] < c.pos[t]) ? 1 : 0;
+        if (rank < kEnvMaxPeaks) dst[rank] = c.pos[t];
+    }
+}
 ECHO_HD double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* smem) {
     if (tid != 0) return;
@@ -531,7 +547,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         if ((p).stop_after == 4) break;                                                                      \
         PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
         if ((p).stop_after == 5) break;                                                                      \
-        PHASE(ph_env_select(tid, nt, p, smem, sm_)) SYNC                                                     \
+        PHASE(ph_env_select(tid, nt, p, smem, sm_); ph_env_peaks_out(tid, nt, blk, p, smem, sm_)) SYNC        \
         PHASE(ph_env_finish(tid, blk, p, smem))                                                              \
     } while (0)
 

@@ -164,6 +164,39 @@ def first_strong_peak(corr, fs=None, min_delay_samples=None):
     return peak, snr
 
 
+def gpu_envelope_detection(signal, method="hilbert", smooth_window=5):
+    """airSonar_optimized.py:431-475 for correlation-length signals (the call at :642): Hilbert envelope,
+    ``uniform_filter1d(smooth_window)``, ``find_peaks(height = mean + 2 std, distance = len // 50, prominence = std)``
+    and ``calculate_signal_quality``.  ``signal``: [L] for one band (band 0's slot is used; the stage does not depend
+    on the band), or [nb, L], or [B, nb, L].  Returns ``(envelope, peaks, quality)`` like the reference for a 1-D
+    input; for batched input ``peaks`` is a list (per row) of index arrays.  Only method='hilbert' with
+    smooth_window=5 runs on the GPU (the band-signal call with window 3 only feeds signal_quality and lives inside
+    ``process_frames(..., mode="full")``)."""
+    if method != "hilbert" or smooth_window != 5:
+        raise ValueError("gpu_envelope_detection: the GPU path implements method='hilbert', smooth_window=5")
+    e = get_engine()
+    like_np = _is_np(signal)
+    x = torch.as_tensor(signal, dtype=torch.float64)
+    nd = x.dim()
+    nb, L = e.cfg.n_bands, e.cfg.n_corr
+    if nd == 1:
+        x3 = x.reshape(1, 1, L).expand(1, nb, L)
+    elif nd == 2:
+        x3 = x.reshape(1, nb, L)
+    else:
+        x3 = x
+    r = e.envelope_detection(x3.contiguous())
+    env, q, pk = r["envelope"], r["quality"], r["peaks"].cpu().numpy()
+    peaks = [[row[row >= 0].astype(np.int64) for row in frame] for frame in pk]
+    if like_np:
+        env, q = env.cpu().numpy(), q.cpu().numpy()
+    if nd == 1:
+        return env[0, 0], peaks[0][0], float(q[0, 0])
+    if nd == 2:
+        return env[0], peaks[0], q[0]
+    return env, peaks, q
+
+
 def calculate_band_confidence(snr, amplitude, band_idx):
     """airSonar_optimized.py:222-243, elementwise on arrays (host arithmetic: three multiplies per element;
     the device path is ``EchoEngine.confidence_fuse``)."""
@@ -201,11 +234,12 @@ class ScalarKalman:
         return float(self._k.update(np.array([z], dtype=np.float64))[0])
 
 
-def process_frames(rx, n_streams=None, kalman: Optional[BatchedKalman] = None, want_spectra=True):
-    """The whole per-frame chain of SonarWorker.run() (airSonar_optimized.py:703-747) for a batch.
+def process_frames(rx, n_streams=None, kalman: Optional[BatchedKalman] = None, want_spectra=True, mode="named"):
+    """The whole per-frame chain of SonarWorker.run() (airSonar_optimized.py:703-747) for a batch; mode="full"
+    includes the Hilbert-envelope branch of _process_band_gpu (:636-654, :670-671).
     Returns (structured records, spec_db or None)."""
     e = get_engine()
-    rec, spec = e.chain(rx, n_streams=n_streams, kalman=kalman, want_spectra=want_spectra)
+    rec, spec = e.chain(rx, n_streams=n_streams, kalman=kalman, want_spectra=want_spectra, mode=mode)
     if _is_np(rx):
         return records_to_numpy(rec), (spec.cpu().numpy() if spec is not None else None)
     return rec, spec

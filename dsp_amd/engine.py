@@ -143,16 +143,17 @@ class EchoEngine:
         """gpu_envelope_detection(corr, 'hilbert', smooth_window=5) + envelope-path peak choice
         (airSonar_optimized.py:431-475, :642-654).  corr [B,nb,L] f64, not modified.
         -> dict(envelope [B,nb,L] f64 or None, peak_idx int32 (-1: fall back to first_strong_peak), snr_db,
-        quality (corr_quality), n_peaks)."""
+        quality (corr_quality), n_peaks, peaks int32 [B,nb,64] ascending, -1 padded)."""
         corr = self._dev(corr, torch.float64)
         B, nb, L = corr.shape
         assert nb == self.cfg.n_bands and L == self.cfg.n_corr
         env = self._empty((B, nb, L), torch.float64) if want_envelope else None
         peak = self._empty((B, nb), torch.int32); npk = self._empty((B, nb), torch.int32)
         snr = self._empty((B, nb), torch.float64); q = self._empty((B, nb), torch.float64)
+        peaks = self._empty((B, nb, 64), torch.int32)
         _lib.check(self.lib.echo_envelope_detection(self._h, _ptr(corr), _ptr(env), _ptr(peak), _ptr(snr), _ptr(q),
-                                                    _ptr(npk), B, self._stream()), "echo_envelope_detection")
-        return dict(envelope=env, peak_idx=peak, snr_db=snr, quality=q, n_peaks=npk)
+                                                    _ptr(npk), _ptr(peaks), B, self._stream()), "echo_envelope_detection")
+        return dict(envelope=env, peak_idx=peak, snr_db=snr, quality=q, n_peaks=npk, peaks=peaks)
 
     def confidence_fuse(self, peak_idx, snr_db, amplitude):
         """Range conversion + band confidence + fusion. -> uint8 tensor [B,64] viewable as RESULT_DTYPE."""

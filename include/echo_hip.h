@@ -129,9 +129,11 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
  * corr[B][nb][L] is the raw correlation and is not modified.  Outputs, each optional (NULL to skip):
  * envelope[B][nb][L] smoothed envelope; peak_idx[B][nb] = valid_peaks[argmax(envelope[valid_peaks])] as an index into
  * corr, or -1 when no peak lies at or beyond min_delay (the caller then falls back to first_strong_peak, :657);
- * snr_db[B][nb] (:652-654); quality[B][nb] = corr_quality; n_peaks[B][nb] = len(corr_peaks). */
+ * snr_db[B][nb] (:652-654); quality[B][nb] = corr_quality; n_peaks[B][nb] = len(corr_peaks);
+ * peaks[B][nb][ECHO_ENV_MAX_PEAKS] = corr_peaks in ascending order, padded with -1. */
+#define ECHO_ENV_MAX_PEAKS 64
 int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
-                            double* quality, int32_t* n_peaks, int B, void* stream);
+                            double* quality, int32_t* n_peaks, int32_t* peaks, int B, void* stream);
 
 /* gpu_argmax (airSonar_optimized.py:359-368): first index of the maximum of each row of x[rows][n]. */
 int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream);

@@ -346,7 +346,13 @@ def test_envelope_detection_against_oracle(gold_default, eng_default):
     r = eng_default.envelope_detection(corr)
     c = corr.cpu().numpy()
     env = r["envelope"].cpu().numpy(); peak = r["peak_idx"].cpu().numpy(); npk = r["n_peaks"].cpu().numpy()
-    snr = r["snr_db"].cpu().numpy(); q = r["quality"].cpu().numpy()
+    snr = r["snr_db"].cpu().numpy(); q = r["quality"].cpu().numpy(); peaks_all = r["peaks"].cpu().numpy()
+    # the reference's function name on one row
+    from dsp_amd import dropin
+    dropin.use_engine(eng_default)
+    e1, p1, q1 = dropin.gpu_envelope_detection(c[0, 1], method="hilbert", smooth_window=5)
+    e_ref, p_ref, q_ref = O.gpu_envelope_detection(c[0, 1], 5)
+    assert np.array_equal(p1, p_ref) and abs(q1 - q_ref) <= 1e-9 and np.abs(e1 - e_ref).max() <= 1e-12 * e_ref.max()
     for f in range(c.shape[0]):
         for b in range(c.shape[1]):
             e, pk, qual = O.gpu_envelope_detection(c[f, b], 5)
@@ -354,6 +360,8 @@ def test_envelope_detection_against_oracle(gold_default, eng_default):
             vp = pk[pk >= cfg.min_delay]
             want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
             assert (want, len(pk)) == (peak[f, b], npk[f, b]), (f, b)
+            got_pk = peaks_all[f, b]
+            assert np.array_equal(got_pk[got_pk >= 0], pk), (f, b)          # corr_peaks, ascending
             assert abs(qual - q[f, b]) <= 1e-9
             if want >= 0:
                 s = 10 * np.log10(e[want] ** 2 / (np.mean(e[:cfg.min_delay] ** 2) + 1e-10))
