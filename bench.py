@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--mode", choices=("named", "full"), default="named",
                     help="'named': the chain the headline metric names (filter + rfft + first_strong_peak + fusion); "
                          "'full': with the reference's Hilbert-envelope branch (secondary measurement)")
-    ap.add_argument("--workload", choices=("optimized", "original", "realtime"), default="optimized",
+    ap.add_argument("--workload", choices=("optimized", "original", "realtime", "twopeak"), default="optimized",
                     help="parameter set; the headline line is 'optimized' (airSonar_optimized.py), the others are "
                          "secondary measurements of the variants (airSonar.py, realtime_sonar.py)")
     return ap.parse_args()
@@ -122,7 +122,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from dsp_amd.config import optimized_config, original_config, realtime_config
+    from dsp_amd.config import optimized_config, original_config, realtime_config, twopeak_config
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.synth import synth_frames
 
@@ -132,7 +132,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config}[args.workload]()
+    cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config,
+           "twopeak": twopeak_config}[args.workload]()
     eng = EchoEngine(cfg, dev)
     B = args.frames
     # batches beyond 4096 frames repeat a 4096-frame pool (the sharded 1M-frame configuration)
@@ -151,7 +152,7 @@ def main():
     # Steady-state pipelining: the input of step k+1 is resident, so its zero-phase IIR (a sequential recurrence that
     # leaves the arithmetic units idle) is started on the engine's own stream as soon as step k has been issued.
     # Each step consumes one prefetched IIR and issues one, so K timed steps do the work of K full chains.
-    pipeline = not args.no_pipeline and args.workload != "original" and B <= 16384
+    pipeline = not args.no_pipeline and args.workload in ("optimized", "realtime") and B <= 16384
 
     def step():
         eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=rec, spec_out=spec, mode=args.mode)

@@ -17,6 +17,8 @@ DET_MEDIAN = 0    # airSonar_optimized.py:200-219  median^2 floor, global argmax
 DET_MAD = 1       # airSonar.py:104-117            first crossing of med + 6*MAD
 DET_MEANPOW = 2   # realtime_sonar.py:127-142      mean-power floor over first 20 % of pos
 
+DET_TWOPEAK = 3   # 666.py:153-200  strongest sample = direct path (time zero), second strongest = echo
+
 # confidence kinds
 CONF_CLAMPED = 0  # airSonar_optimized.py:222-243  per-term min(.,1)
 CONF_RAW = 1      # realtime_sonar.py:393          only the final min(.,1)
@@ -26,6 +28,9 @@ CONF_NONE = 2     # airSonar.py has no confidence
 FUSE_WEIGHTED_EPS = 0  # airSonar_optimized.py:733-738  weights = norm/100 + 1e-9
 FUSE_WEIGHTED = 1      # realtime_sonar.py:337-339      weights = norm/100
 FUSE_MEAN = 2          # airSonar.py:203-206            plain mean of valid distances
+FUSE_SNRNORM = 3       # 666.py:372-385                 weights = snr / max(snr) * 100 + 1e-9
+
+BANDS_TWOPEAK = ((3000, 7000), (10000, 14000), (17000, 20000))      # 666.py:68
 
 BANDS_DEFAULT = ((3000, 5000), (3000, 5000), (3000, 5000))          # airSonar_optimized.py:75
 BANDS_DISTINCT = ((9500, 11500), (13500, 15500), (17500, 19500))    # airSonar_optimized.py:74 (commented), realtime_sonar.py:60
@@ -106,7 +111,7 @@ class SonarConfig:
 
     @property
     def noise_n(self) -> int:
-        if self.DETECTOR == DET_MEANPOW:         # realtime_sonar.py:135
+        if self.DETECTOR in (DET_MEANPOW, DET_TWOPEAK):   # realtime_sonar.py:135, 666.py:180
             return int(self.n_pos * 0.2)
         return int(self.SNR_NOISE_MS * self.FS)  # airSonar_optimized.py:209
 
@@ -142,6 +147,14 @@ def original_config() -> SonarConfig:
                        CHIRP_LEN_FIXED=0.1, LISTEN_LEN_FIXED=0.2, MIN_DELAY_FIXED=500,
                        DETECTOR=DET_MAD, CONFIDENCE=CONF_NONE, FUSION=FUSE_MEAN,
                        SUBTRACT_CHIRP=False, KALMAN_Q=0.01, KALMAN_R=0.2)
+
+
+def twopeak_config() -> SonarConfig:
+    """666.py parameters: FS 48000, 0.05 s chirp (M = 2400), 0.15 s listen (N = 7200), IIR 6 / FIR 61, two-peak
+    detector (delay = echo peak - direct-path peak), clamped confidence, SNR-normalised fusion
+    (666.py:57-68, :114-128, :153-200, :372-385, :425-443)."""
+    return SonarConfig(BANDS=BANDS_TWOPEAK, CHIRP_LEN_FIXED=0.05, LISTEN_LEN_FIXED=0.15, MIN_DELAY_FIXED=0,
+                       DETECTOR=DET_TWOPEAK, CONFIDENCE=CONF_CLAMPED, FUSION=FUSE_SNRNORM, SUBTRACT_CHIRP=False)
 
 
 def realtime_config() -> SonarConfig:

@@ -98,7 +98,8 @@ int ensure_scratch(EchoHandle* h, int frames) {
         (!h->long_path && hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess) ||
         (h->long_path && (hipMalloc(reinterpret_cast<void**>(&h->d_band), y_n * sizeof(double)) != hipSuccess ||
                           hipMalloc(reinterpret_cast<void**>(&h->d_pos), (size_t)frames * c.n_bands *
-                                    (size_t)(h->lbase.L - h->lbase.half) * sizeof(double)) != hipSuccess)) ||
+                                    (size_t)(c.detector == ECHO_DET_TWOPEAK ? h->lbase.L : h->lbase.L - h->lbase.half) *
+                                    sizeof(double)) != hipSuccess)) ||
         hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_env), (size_t)frames * c.n_bands * sizeof(EnvRes)) != hipSuccess ||
@@ -170,6 +171,7 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
     p.res = res; p.out = out; p.fused = fused; p.valid_any = vany;
     p.B = B; p.nb = h->cfg.n_bands; p.fs = h->cfg.fs; p.range_offset = h->cfg.range_offset;
     p.confidence = h->cfg.confidence; p.fusion = h->cfg.fusion; p.sound_speed = h->cfg.sound_speed;
+    p.detector = h->cfg.detector;
     for (int j = 0; j < 3; ++j) p.fw[j] = h->cfg.freq_weights[j];
     p.env = nullptr; p.sq = nullptr; p.quality_out = nullptr;
     return p;
@@ -177,7 +179,7 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
 
 bool detector_supported(const EchoHandle* h) {
     const int d = h->cfg.detector;
-    return h->long_path ? d == ECHO_DET_MAD : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
+    return h->long_path ? (d == ECHO_DET_MAD || d == ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
 }
 
 }  // namespace
@@ -216,7 +218,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     std::memset(&h->base, 0, sizeof(h->base));
     const bool fits = plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay,
                                 cfg->noise_n, cfg->detector, cfg->snr_gate_db);
-    h->long_path = !fits || cfg->detector == ECHO_DET_MAD;
+    h->long_path = !fits || cfg->detector == ECHO_DET_MAD || cfg->detector == ECHO_DET_TWOPEAK;
     std::memset(&h->lbase, 0, sizeof(h->lbase));
     if (h->long_path) {
         if (!plan_long(h->lbase, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay, cfg->detector)) {
@@ -224,6 +226,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             return ECHO_ERR_UNSUPPORTED;
         }
         h->max_chunk = std::min(4096, 65535 / cfg->n_bands);
+        h->lbase.noise_n = cfg->noise_n; h->lbase.snr_gate = cfg->snr_gate_db;
     }
     const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
     h->bodd0 = true;
@@ -558,10 +561,12 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_long_fir(q, n, s);
             if (rc) return rc;
             q.band_in = h->d_band; q.corr_out = h->d_pos;
-            q.k_begin = std::min(q.half + q.min_delay, q.L - 1); q.corr_k0 = q.half; q.corr_stride = q.L - q.half;
+            const bool all_lags = q.detector == ECHO_DET_TWOPEAK;       // its amplitude is max|corr| over every lag
+            q.k_begin = all_lags ? 0 : std::min(q.half + q.min_delay, q.L - 1);
+            q.corr_k0 = all_lags ? 0 : q.half; q.corr_stride = all_lags ? q.L : q.L - q.half;
             rc = launch_long_corr(q, n, s);
             if (rc) return rc;
-            q.det_io = h->d_pos; q.det_stride = q.L - q.half; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
+            q.det_io = h->d_pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
             rc = launch_long_detect(q, n, s);
             if (rc) return rc;
             if (spec_db) {

@@ -26,7 +26,7 @@ struct FuseParams {
     void* out;            // EchoResult[B]
     double* fused;        // [B] (may be null)
     uint8_t* valid_any;   // [B] (may be null)
-    int B, nb, fs, range_offset, confidence, fusion;
+    int B, nb, fs, range_offset, confidence, fusion, detector;
     double sound_speed;
     double fw[3];
     // full chain (envelope branch): per (frame, band) envelope results and signal quality; null = named chain

@@ -17,7 +17,7 @@ __global__ void fuse_kernel(FuseParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.B) return;
     EchoResult r;
-    double d[ECHO_MAX_BANDS], c[ECHO_MAX_BANDS];
+    double d[ECHO_MAX_BANDS], c[ECHO_MAX_BANDS], sn[ECHO_MAX_BANDS];
     int nvalid = 0;
     r.valid_mask = 0;
     for (int j = 0; j < ECHO_MAX_BANDS; ++j) { r.dist[j] = 0.f; r.conf[j] = 0.f; r.snr_db[j] = 0.f; r.peak_idx[j] = -1; }
@@ -37,8 +37,10 @@ __global__ void fuse_kernel(FuseParams p) {
                 p.quality_out[((size_t)i * p.nb + j) * 2 + 1] = e.quality;
             }
         }
-        r.peak_idx[j] = br.peak_idx;
-        if (br.peak_idx < 0) continue;
+        // the two-peak detector reports a delay that may be zero or negative; its validity travels in `pad`
+        const bool band_valid = p.detector == ECHO_DET_TWOPEAK ? br.pad != 0 : br.peak_idx >= 0;
+        r.peak_idx[j] = band_valid ? br.peak_idx : -1;
+        if (!band_valid) continue;
         const double delay = (double)(br.peak_idx - p.range_offset);
         const double dist = delay / (double)p.fs * p.sound_speed / 2.0;
         double conf = 0.0;
@@ -52,7 +54,7 @@ __global__ void fuse_kernel(FuseParams p) {
         if (p.env) conf = conf * (0.5 + 0.5 * qfactor);
         r.dist[j] = (float)dist; r.conf[j] = (float)conf; r.snr_db[j] = (float)br.snr_db;
         r.valid_mask |= 1u << j;
-        d[nvalid] = dist; c[nvalid] = conf; ++nvalid;
+        d[nvalid] = dist; c[nvalid] = conf; sn[nvalid] = br.snr_db; ++nvalid;
     }
     double fused = 0.0, avg = 0.0;
     if (nvalid > 0) {
@@ -60,6 +62,18 @@ __global__ void fuse_kernel(FuseParams p) {
             double s = 0.0;
             for (int k = 0; k < nvalid; ++k) s += d[k];
             fused = s / (double)nvalid;
+        } else if (p.fusion == ECHO_FUSE_SNRNORM) {
+            // 666.py:372-385: SNRs scaled so that the largest is 100 (zeros when none is positive), + 1e-9 as weights
+            double mx = sn[0];
+            for (int k = 1; k < nvalid; ++k) mx = sn[k] > mx ? sn[k] : mx;
+            double sw = 0.0, swd = 0.0, sn_sum = 0.0;
+            for (int k = 0; k < nvalid; ++k) {
+                const double nk = mx > 0.0 ? sn[k] / mx * 100.0 : 0.0;
+                const double w = nk + 1e-9;
+                swd += d[k] * w; sw += w; sn_sum += nk;
+            }
+            fused = swd / sw;
+            avg = sn_sum / (double)nvalid;
         } else {
             double total = 0.0;
             for (int k = 0; k < nvalid; ++k) total += c[k];

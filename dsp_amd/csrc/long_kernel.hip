@@ -35,6 +35,18 @@ __global__ __launch_bounds__(kLDetNT) void long_detect_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
+__global__ __launch_bounds__(kLDetNT) void long_twopeak_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    ph_tp_load(tid, kLDetNT, blk, p, smem);
+    __syncthreads();
+    ph_tp_ref(tid, kLDetNT, p, smem);
+    __syncthreads();
+    ph_tp_second(tid, kLDetNT, p, smem);
+    __syncthreads();
+    ph_tp_finish(tid, kLDetNT, blk, p, smem);
+}
+
 __global__ __launch_bounds__(kLSpecNT) void long_spec_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
@@ -58,6 +70,8 @@ int long_kernels_prepare(const LongParams& p) {
                             p.corr_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(long_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             p.det_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(long_twopeak_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.tp_smem) != hipSuccess ||
         (p.has_spec && hipFuncSetAttribute(reinterpret_cast<const void*>(long_spec_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.spec_smem) != hipSuccess))
         return ECHO_ERR_HIP;
@@ -92,6 +106,10 @@ int launch_long_spec(const LongParams& p, int B, hipStream_t s) {
 
 int launch_long_detect(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
+    if (p.detector == ECHO_DET_TWOPEAK) {
+        hipLaunchKernelGGL(long_twopeak_kernel, dim3(B * p.nb), dim3(kLDetNT), p.tp_smem, s, p);
+        return ok();
+    }
     hipLaunchKernelGGL(long_detect_kernel, dim3(B * p.nb), dim3(kLDetNT), p.det_smem, s, p);
     return ok();
 }

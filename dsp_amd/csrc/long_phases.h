@@ -55,8 +55,10 @@ struct LongParams {
     const cpx<float>* suk;           // global: n2 + 1, exp(-2*pi*i*k/N)
     const double* spec_in;           // [B][nb][N]
     float* spec_out;                 // [B][nb][nbins]
+    int noise_n;                     // two-peak detector: length of the noise region of pos
+    double snr_gate;
     // LDS sizes
-    int fir_smem, corr_smem, det_smem, spec_smem;
+    int fir_smem, corr_smem, det_smem, spec_smem, tp_smem;
 };
 
 struct DetMisc {                     // detector scalars in LDS
@@ -75,6 +77,7 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.corr_smem = (N + 2 * kLPad) * 8 + (p.mgroups + 1) * kR * 8;
     const int npos = p.L - p.half;
     p.det_smem = ((npos + 1) & ~1) * 8 + 256 * 4 + (int)sizeof(DetMisc);
+    p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;
     p.n2 = N / 2; p.nbins = N / 2 + 1;
     p.has_spec = (N % 2 == 0) && gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
     p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
@@ -295,6 +298,82 @@ ECHO_HD void ph_ldet_finish(int tid, int blk, const LongParams& p, unsigned char
     r.snr_db = 0.0; r.amplitude = 0.0; r.pad = 0;
     r.peak_idx = m->first == 0x7fffffff ? -1 : m->first;
     p.res_out[blk] = r;
+}
+
+// ---------------------------------------------------------------- two-peak detector (666.py:153-200)
+// pos = corr[half:]; ref = argmax(pos) is the direct path; pos2 = pos with pos2[ref] = 0; peak = argmax(pos2);
+// noise floor = mean(pos2[:noise_n]^2); snr = 10 log10(pos2[peak]^2 / noise floor) (0 when the floor is 0); None when
+// pos2 is all zero or snr < gate; delay = peak - ref.  amplitude = max|corr| over every lag (666.py:439).
+// LDS: double pos[npos], then scratch double a[nt], double b[nt], int i[nt] (as doubles), then TpMisc.
+struct TpMisc { double best, amp, noise, best2; int ref, peak, nonzero, pad; };
+ECHO_HD double* tp_scratch(const LongParams& p, unsigned char* smem) {
+    return reinterpret_cast<double*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
+}
+ECHO_HD TpMisc* tp_misc(const LongParams& p, unsigned char* smem, int nt) {
+    return reinterpret_cast<TpMisc*>(tp_scratch(p, smem) + 3 * nt);
+}
+// pass 1: stage pos, per-thread argmax of pos (first index on ties) and max|corr| over all lags
+ECHO_HD void ph_tp_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    double* pos = det_pos(smem);
+    const double* corr = p.det_io + (size_t)blk * p.det_stride;
+    const int npos = p.L - p.half;
+    double best = -INFINITY, amp = 0.0;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < p.L; k += nt) {
+        const double v = corr[k], av = fabs(v);
+        amp = av > amp ? av : amp;
+        if (k >= p.half) {
+            const int q = k - p.half;
+            pos[q] = v;
+            if (v > best) { best = v; bi = q; }        // ascending q per thread: the first index wins ties
+        }
+    }
+    (void)npos;
+    double* sc = tp_scratch(p, smem);
+    sc[tid] = best; sc[nt + tid] = amp; reinterpret_cast<int*>(sc + 2 * nt)[tid] = bi;
+}
+ECHO_HD void tp_better(double& b, int& i, double b2, int i2) { if (b2 > b || (b2 == b && i2 < i)) { b = b2; i = i2; } }
+ECHO_HD void ph_tp_ref(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const double* sc = tp_scratch(p, smem);
+    const int* si = reinterpret_cast<const int*>(sc + 2 * nt);
+    TpMisc* m = tp_misc(p, smem, nt);
+    double best = sc[0], amp = sc[nt]; int bi = si[0];
+    for (int t = 1; t < nt; ++t) { tp_better(best, bi, sc[t], si[t]); amp = sc[nt + t] > amp ? sc[nt + t] : amp; }
+    m->best = best; m->ref = bi; m->amp = amp;
+}
+// pass 2 over pos2: argmax, any nonzero, noise power
+ECHO_HD void ph_tp_second(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    const double* pos = det_pos(smem);
+    const TpMisc* m = tp_misc(p, smem, nt);
+    const int npos = p.L - p.half, ref = m->ref;
+    double best = -INFINITY, noise = 0.0; int bi = 0x7fffffff, nz = 0;
+    for (int q = tid; q < npos; q += nt) {
+        const double v = q == ref ? 0.0 : pos[q];
+        if (v > best) { best = v; bi = q; }
+        nz |= (v != 0.0) ? 1 : 0;
+        if (q < p.noise_n) noise += v * v;
+    }
+    double* sc = tp_scratch(p, smem);
+    int* si = reinterpret_cast<int*>(sc + 2 * nt);
+    sc[tid] = best; sc[nt + tid] = noise; si[tid] = (bi << 1) | nz;      // bi < 2^30
+}
+ECHO_HD void ph_tp_finish(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const double* sc = tp_scratch(p, smem);
+    const int* si = reinterpret_cast<const int*>(sc + 2 * nt);
+    const TpMisc* m = tp_misc(p, smem, nt);
+    double best = sc[0], noise = sc[nt]; int bi = si[0] >> 1, nz = si[0] & 1;
+    for (int t = 1; t < nt; ++t) { tp_better(best, bi, sc[t], si[t] >> 1); noise += sc[nt + t]; nz |= si[t] & 1; }
+    BandRes r;
+    r.amplitude = m->amp; r.snr_db = 0.0; r.peak_idx = -1; r.pad = 0;
+    const int npos = p.L - p.half;
+    if (npos > 0 && nz) {
+        const double floor_ = p.noise_n > 0 ? noise / (double)p.noise_n : 0.0;
+        const double snr = floor_ > 0.0 ? 10.0 * log10(best * best / floor_) : 0.0;
+        if (!(snr < p.snr_gate)) { r.snr_db = snr; r.peak_idx = bi - m->ref; r.pad = 1; }
+    }
+    if (p.res_out) p.res_out[blk] = r;
 }
 
 // The barrier-separated sequence of one detector workgroup; SYNC is __syncthreads() on the device and the end of a

@@ -38,13 +38,16 @@ enum {
 /* detector / confidence / fusion variants (the three first_strong_peak generations the reference ships) */
 enum { ECHO_DET_MEDIAN = 0,   /* airSonar_optimized.py:200-219 */
        ECHO_DET_MAD = 1,      /* airSonar.py:104-117           */
-       ECHO_DET_MEANPOW = 2   /* realtime_sonar.py:127-142     */ };
+       ECHO_DET_MEANPOW = 2,  /* realtime_sonar.py:127-142     */
+       ECHO_DET_TWOPEAK = 3   /* 666.py:153-200: peak_idx is the delay echo - direct path and may be <= 0;
+                                 validity is carried by valid_mask (chain) or snr_db > 0 (first_strong_peak) */ };
 enum { ECHO_CONF_CLAMPED = 0, /* airSonar_optimized.py:222-243 */
        ECHO_CONF_RAW = 1,     /* realtime_sonar.py:393         */
        ECHO_CONF_NONE = 2 };
 enum { ECHO_FUSE_WEIGHTED_EPS = 0, /* airSonar_optimized.py:733-738 */
        ECHO_FUSE_WEIGHTED = 1,     /* realtime_sonar.py:336-339     */
-       ECHO_FUSE_MEAN = 2 };       /* airSonar.py:203-205           */
+       ECHO_FUSE_MEAN = 2,         /* airSonar.py:203-205           */
+       ECHO_FUSE_SNRNORM = 3 };    /* 666.py:372-385: weights = snr / max(snr) * 100 + 1e-9 */
 
 /* Host-side description of one sonar configuration; replaces the module-global `cfg` plus the
  * results of design_filters()/generate_chirps() (airSonar_optimized.py:65-113, :157-183).

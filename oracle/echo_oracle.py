@@ -23,9 +23,9 @@ import numpy as np
 from scipy.signal import correlate, fftconvolve, filtfilt, find_peaks, hilbert, lfilter_zi
 from scipy.ndimage import uniform_filter1d
 
-DET_MEDIAN, DET_MAD, DET_MEANPOW = 0, 1, 2
+DET_MEDIAN, DET_MAD, DET_MEANPOW, DET_TWOPEAK = 0, 1, 2, 3
 CONF_CLAMPED, CONF_RAW, CONF_NONE = 0, 1, 2
-FUSE_WEIGHTED_EPS, FUSE_WEIGHTED, FUSE_MEAN = 0, 1, 2
+FUSE_WEIGHTED_EPS, FUSE_WEIGHTED, FUSE_MEAN, FUSE_SNRNORM = 0, 1, 2, 3
 
 
 # --------------------------------------------------------------------------- filtering
@@ -164,6 +164,29 @@ def first_strong_peak_mad(corr, fs, min_delay_samples=500):
     return int(idxs[0])
 
 
+def first_strong_peak_twopeak(corr, fs):
+    """666.py:153-200: the strongest sample of pos = corr[half:] is the direct path (time zero); it is zeroed in a
+    copy and the strongest remaining sample is the echo.  Noise floor = mean power of the first 20 % of that copy,
+    6 dB gate.  Returns (delay_samples = echo index - direct index, snr_db) or (None, 0.0)."""
+    half = corr.size // 2
+    pos = corr[half:]
+    if pos.size == 0:
+        return None, 0.0
+    ref_idx = np.argmax(pos)
+    pos2 = pos.copy()
+    pos2[ref_idx] = 0
+    if np.all(pos2 == 0):
+        return None, 0.0
+    peak_idx = np.argmax(pos2)
+    noise_region = int(len(pos2) * 0.2)
+    noise_floor = np.mean(pos2[:noise_region] ** 2) if noise_region > 0 else 0.0
+    peak_power = pos2[peak_idx] ** 2
+    snr_db = 10 * np.log10(peak_power / noise_floor) if noise_floor > 0 else 0.0
+    if snr_db < 6.0:
+        return None, 0.0
+    return int(peak_idx - ref_idx), float(snr_db)
+
+
 # --------------------------------------------------------------------------- confidence / fusion / Kalman
 def calculate_band_confidence(snr, amplitude, band_idx, freq_weights=(0.8, 1.0, 0.9)):
     """airSonar_optimized.py:222-243."""
@@ -219,6 +242,11 @@ def fuse(results, cfg):
     distances, confidences, snrs = zip(*results)
     if cfg.FUSION == FUSE_MEAN:
         return float(np.mean(distances)), 0.0, np.zeros(len(distances))
+    if cfg.FUSION == FUSE_SNRNORM:                       # 666.py:372-385
+        snr_array = np.array(snrs)
+        normalized = snr_array / np.max(snr_array) * 100 if np.max(snr_array) > 0 else np.zeros_like(snr_array)
+        weights = normalized + 1e-9
+        return float(np.average(distances, weights=weights)), float(np.mean(normalized)), normalized
     conf_norm = normalize_confidences(confidences)
     weights = conf_norm / 100.0
     if cfg.FUSION == FUSE_WEIGHTED_EPS:
@@ -298,6 +326,8 @@ def process_band(rx, chirp_sig, filt, band_idx, cfg, mode="named"):
             peak_idx, snr = first_strong_peak(corr, fs, cfg, min_delay)
         elif cfg.DETECTOR == DET_MEANPOW:
             peak_idx, snr = first_strong_peak_meanpow(corr, fs, cfg, min_delay)
+        elif cfg.DETECTOR == DET_TWOPEAK:
+            peak_idx, snr = first_strong_peak_twopeak(corr, fs)
         else:
             peak_idx = first_strong_peak_mad(corr, fs, min_delay)
             snr = 0.0

@@ -35,6 +35,11 @@ def gold_original():
 
 
 @pytest.fixture(scope="session")
+def gold_twopeak():
+    return load_golden("twopeak")
+
+
+@pytest.fixture(scope="session")
 def gold_realtime():
     return load_golden("realtime")
 

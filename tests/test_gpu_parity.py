@@ -458,3 +458,41 @@ def test_prefetched_iir_pipeline_matches_plain_calls(mode, eng_default):
     rec, spec = eng_default.chain(batches[1], mode=mode)
     assert torch.equal(rec, want[1][0]) and torch.equal(spec, want[1][1])
     assert eng_default.prefetch_ms() > 0
+
+
+def test_twopeak_variant_goldens_and_oracle(gold_twopeak):
+    """666.py parameters (N = 7200, M = 2400; strongest sample = direct path, second strongest = echo, delay may be
+    zero or negative; SNR-normalised fusion) on the long-frame kernels.  Validity is read from valid_mask."""
+    from dsp_amd.engine import BatchedKalman
+    g = gold_twopeak
+    cfg = C.twopeak_config()
+    e = _engine(cfg)
+
+    def check(rec, exp):
+        r = _rec(rec)
+        valid = ((r["valid_mask"][:, None] >> np.arange(3)) & 1).astype(bool)
+        assert np.array_equal(valid, exp["valid"])
+        v = exp["valid"]
+        assert np.array_equal(r["peak_idx"][v], exp["peak_idx"][v])          # delays, bit-exact (negative ones included)
+        np.testing.assert_allclose(r["dist"][v], exp["distance"][v], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(r["snr_db"][v], exp["snr_db"][v], rtol=RTOL)
+        np.testing.assert_allclose(r["conf"][v], exp["confidence"][v], rtol=RTOL)
+        va = exp["valid_any"]
+        np.testing.assert_allclose(r["fused_dist"][va], exp["fused_dist"][va], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(r["avg_conf"][va], exp["avg_conf"][va], rtol=RTOL)
+        np.testing.assert_allclose(r["kalman"], exp["kalman"], rtol=RTOL, atol=1e-7)
+
+    rec, _ = e.chain(rx_from_i16(g["rx_i16"]), n_streams=1, kalman=BatchedKalman(e, 1), want_spectra=False)
+    check(rec, g)
+    t = build_tables(cfg)
+    rxs = synth_frames(48, cfg, t.tx_pcm)
+    o = O.chain(rxs, t.chirps_f32, t.filters, cfg, n_streams=4, mode="named")
+    rec, _ = e.chain(rxs, n_streams=4, kalman=BatchedKalman(e, 4), want_spectra=False)
+    check(rec, o)
+    # standalone detector on the golden correlation: delay, snr > 0 marks validity, corr untouched
+    c = torch.from_numpy(g["stage_corr0"].copy()[None]).to(e.device)
+    peak, snr, amp = e.first_strong_peak(c)
+    assert np.array_equal(peak[0].cpu().numpy(), g["peak_idx"][0]) and (snr[0].cpu().numpy() > 0).all()
+    np.testing.assert_allclose(amp[0].cpu().numpy(), g["amplitude"][0], rtol=1e-12)
+    assert np.array_equal(c[0].cpu().numpy(), g["stage_corr0"])
+    e.close()

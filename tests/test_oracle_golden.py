@@ -119,3 +119,18 @@ def test_oracle_realtime(gold_realtime):
     for k in ("peak_idx", "snr_db", "amplitude", "distance", "confidence", "valid", "fused_dist",
               "avg_conf", "valid_any", "kalman"):
         assert np.array_equal(r[k], g[k]), k
+
+
+def test_oracle_twopeak(gold_twopeak):
+    """666.py: two-peak detector (delay = echo peak - direct-path peak, may be negative), SNR-normalised fusion."""
+    g = gold_twopeak
+    cfg = C.twopeak_config()
+    t = build_tables(cfg)
+    assert np.array_equal(t.tx_pcm, g["tx_pcm"]) and np.array_equal(np.stack(t.chirps_f32), g["chirps"])
+    assert (cfg.n_rx, cfg.n_chirp, cfg.n_corr, cfg.half, cfg.noise_n) == (7200, 2400, 9599, 4799, 960)
+    rx = rx_from_i16(g["rx_i16"])
+    r = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=1, mode="named")
+    for k in ("peak_idx", "snr_db", "amplitude", "distance", "confidence", "valid", "fused_dist",
+              "avg_conf", "valid_any", "kalman"):
+        assert np.array_equal(r[k], g[k]), k
+    assert (g["peak_idx"][g["valid"]] < 0).any()          # the fixture does contain valid negative delays

@@ -242,9 +242,77 @@ def run_realtime(n_streams=4, n_steps=6):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "valid", int(valid.sum()), "of", valid.size)
 
 
+def run_twopeak(n_random=6):
+    """666.py: two-peak detector (direct path = time zero), SNR-normalised fusion; N = 7200, M = 2400."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref666", "/root/reference/666.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cfg = C.twopeak_config()
+    tx_pcm, chirps = ref.generate_chirps()
+    filters = ref.design_filters()
+    assert len(tx_pcm) == cfg.n_chirp and int(ref.FS * ref.LISTEN_LEN) == cfg.n_rx
+    tx_mix = tx_pcm.astype(np.float64) / 32768.0
+    rng = np.random.default_rng(666)
+    frames = []
+    for i in range(n_random):
+        # direct-path pulse near the start (what the detector calls time zero) plus the synthetic echo frame
+        q = synth_frame_i16(i, cfg, tx_mix).astype(np.float64) / 32768.0
+        d0 = int(rng.integers(0, 200))
+        q[d0:d0 + cfg.n_chirp] += 0.5 * tx_mix[:cfg.n_rx - d0][:cfg.n_chirp]
+        frames.append(quantise(q))
+    frames.append(quantise(np.zeros(cfg.n_rx)))
+    frames.append(synth_frame_i16(99, cfg, tx_mix))            # echo only, no direct path
+    rx_i16 = np.stack(frames)
+    rx = rx_i16.astype(np.float32) / 2 ** 15
+    B, nb = len(rx), len(filters)
+    delay = np.full((B, nb), -1, np.int32); snr = np.zeros((B, nb)); dist = np.zeros((B, nb))
+    conf = np.zeros((B, nb)); valid = np.zeros((B, nb), bool); amp = np.zeros((B, nb))
+    fused = np.zeros(B); avgc = np.zeros(B); vany = np.zeros(B, bool); kal = np.zeros(B)
+    band0 = np.zeros((nb, cfg.n_rx)); corr0 = np.zeros((nb, cfg.n_corr))
+    kf = ref.ScalarKalman(); me = _Self()
+    for i in range(B):
+        res = []
+        for j in range(nb):
+            y = ref.bandpass(rx[i], filters[j])
+            corr = ref.correlate(y, chirps[j], 'full')
+            if i == 0:
+                band0[j] = y; corr0[j] = corr
+            amp[i, j] = np.max(np.abs(corr))
+            dl, s = ref.first_strong_peak(corr, ref.FS)
+            d, c, s2 = ref.SonarWorker._process_band(me, rx[i], chirps[j], filters[j], j)
+            if dl is not None:
+                delay[i, j] = dl; snr[i, j] = s; valid[i, j] = True; dist[i, j] = d; conf[i, j] = c
+                res.append((d, c, s2))
+            else:
+                assert d is None
+        if res:
+            distances, confs, snrs = zip(*res)
+            snr_array = np.array(snrs)                                     # 666.py:372-385
+            normalized = snr_array / np.max(snr_array) * 100 if np.max(snr_array) > 0 else np.zeros_like(snr_array)
+            weights = normalized + 1e-9
+            fused[i] = np.average(distances, weights=weights); avgc[i] = np.mean(normalized); vany[i] = True
+            kal[i] = kf.update(fused[i])
+        else:
+            kal[i] = kf.x if kf.x is not None else 0.0
+    path = os.path.join(GOLD, "twopeak.npz")
+    np.savez_compressed(path, rx_i16=rx_i16, tx_pcm=tx_pcm, chirps=np.stack(chirps),
+                        filt_b=np.stack([f[0] for f in filters]), filt_a=np.stack([f[1] for f in filters]),
+                        filt_taps=np.stack([f[2] for f in filters]),
+                        peak_idx=delay, snr_db=snr, amplitude=amp, distance=dist, confidence=conf, valid=valid,
+                        fused_dist=fused, avg_conf=avgc, valid_any=vany, kalman=kal,
+                        stage_band_sig0=band0, stage_corr0=corr0,
+                        numpy_version=np.__version__, scipy_version=scipy.__version__)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "valid", int(valid.sum()), "of", valid.size)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "twopeak":      # only the 666.py variant
+        run_twopeak()
+        sys.exit(0)
     run_optimized("default", C.BANDS_DEFAULT)
     run_optimized("distinct", C.BANDS_DISTINCT)
     run_original()
     run_realtime()
+    run_twopeak()
