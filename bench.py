@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
                     help="internal: run the CPU oracle on one frame shard and print the seconds taken")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
+    ap.add_argument("--device-synth", action="store_true",
+                    help="generate the batch in device memory (every frame distinct, no upload); the CPU baseline "
+                         "then runs on frames downloaded from the device")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not start the next step's IIR on the engine's own stream during the current step")
     ap.add_argument("--mode", choices=("named", "full"), default="named",
@@ -137,10 +140,14 @@ def main():
     eng = EchoEngine(cfg, dev)
     B = args.frames
     # batches beyond 4096 frames repeat a 4096-frame pool (the sharded 1M-frame configuration)
-    rx_host = synth_frames(min(B, 4096), cfg, eng.tables.tx_pcm, start=rank * min(B, 4096))
-    rx = torch.from_numpy(rx_host).to(dev)
-    if B > 4096:
-        rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
+    if args.device_synth:
+        rx = eng.synth_frames(B, first_frame=rank * B)
+        rx_host = rx[:min(B, 4096)].cpu().numpy()
+    else:
+        rx_host = synth_frames(min(B, 4096), cfg, eng.tables.tx_pcm, start=rank * min(B, 4096))
+        rx = torch.from_numpy(rx_host).to(dev)
+        if B > 4096:
+            rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
     S = N_STREAMS if B % N_STREAMS == 0 else 1
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
@@ -203,7 +210,7 @@ def main():
             "metric": "echo frames/sec (3-band filter+rfft+peak)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic (generated on the device)" if args.device_synth else "synthetic",
             "config": {"workload": (f"configs[1]: " if args.workload == "optimized" else f"variant '{args.workload}': ")
                                    + f"{B} synthetic rx frames per GPU per step, {cfg.n_bands} bands, N={cfg.n_rx}, "
                                    f"M={cfg.n_chirp}, IIR order {cfg.IIR_ORDER} (filtfilt) + FIR {cfg.FIR_TAPS}, "

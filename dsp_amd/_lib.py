@@ -15,7 +15,7 @@ EXPORTS = [
     "echo_create", "echo_destroy", "echo_reserve", "echo_strerror", "echo_version",
     "echo_fir_bank", "echo_bandpass_bank", "echo_spectrum", "echo_mag2db", "echo_correlate",
     "echo_first_strong_peak", "echo_envelope_detection", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
-    "echo_chain", "echo_chain_full", "echo_chain_prefetch", "echo_prefetch_ms", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
+    "echo_synth_frames", "echo_chain", "echo_chain_full", "echo_chain_prefetch", "echo_prefetch_ms", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
     "echo_set_profiling", "echo_last_kernel_ms",
 ]
 
@@ -65,6 +65,7 @@ def load():
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain_full.argtypes = [P, P, P, P, P, P, P, P, I, I, P]
+    lib.echo_synth_frames.argtypes = [P, P, P, I, C.c_longlong, C.c_ulonglong, P]
     lib.echo_chain_prefetch.argtypes = [P, P, I]
     lib.echo_prefetch_ms.argtypes = [P, C.POINTER(C.c_float)]
     lib.echo_graph_create.argtypes = [P, P, P, P, P, P, P, I, I, P, C.POINTER(P)]

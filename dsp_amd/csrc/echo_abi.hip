@@ -645,6 +645,20 @@ int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec
     return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
 }
 
+int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long long first_frame,
+                      unsigned long long seed, void* stream) {
+    if (!h || !tx_mix || !rx || B < 0 || first_frame < 0) return ECHO_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = h->cfg.n_rx;
+    for (int f0 = 0; f0 < B; f0 += 65535) {                 // one workgroup per frame
+        const int n = std::min(65535, B - f0);
+        const int rc = launch_synth(rx + (size_t)f0 * N, tx_mix, n, N, h->cfg.n_chirp, h->cfg.fs, first_frame + f0, seed,
+                                    343.42f, s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
 int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
     if (!h || !rx || B < 1) return ECHO_ERR_INVALID;
     if (h->long_path || B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;

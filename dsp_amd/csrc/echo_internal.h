@@ -59,6 +59,8 @@ int env_kernel_prepare(const EnvParams& p);
 int launch_corr_env(const EnvParams& p, int B, hipStream_t s);
 int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,
                       hipStream_t s);
+int launch_synth(float* rx, const float* tx_mix, int B, int N, int M, int fs, long long first, unsigned long long seed,
+                 float c_sound, hipStream_t s);
 int launch_pack_res(const int32_t* peak, const double* snr, const double* amp, BandRes* res, int n, hipStream_t s);
 int launch_unpack_res(const BandRes* res, int32_t* peak, double* snr, double* amp, int n, hipStream_t s);
 int launch_fuse(const FuseParams& p, hipStream_t s);

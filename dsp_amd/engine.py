@@ -194,6 +194,17 @@ class EchoEngine:
                                            B, S, self._stream()), "echo_chain")
         return out, spec
 
+    def synth_frames(self, count: int, first_frame: int = 0, seed: int = 1234, out=None) -> torch.Tensor:
+        """``count`` synthetic rx frames generated in device memory (frame g = a function of (seed, g)); float32
+        [count, n_rx] on the int16 grid.  Same recipe as dsp_amd.synth with its own random stream."""
+        if getattr(self, "_tx_mix_dev", None) is None:
+            self._tx_mix_dev = torch.from_numpy((self.tables.tx_pcm.astype(np.float64) / 32768.0).astype(np.float32)
+                                                ).to(self.device)
+        rx = out if out is not None else self._empty((count, self.cfg.n_rx), torch.float32)
+        _lib.check(self.lib.echo_synth_frames(self._h, _ptr(self._tx_mix_dev), _ptr(rx), count, first_frame, seed,
+                                              self._stream()), "echo_synth_frames")
+        return rx
+
     def chain_prefetch(self, rx: torch.Tensor):
         """Start the IIR of the batch the next ``chain`` call will get (same tensor), on the engine's own stream, so it
         overlaps the current batch's kernels.  ``rx`` must be a complete, contiguous float32 device tensor [B, N]

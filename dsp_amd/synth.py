@@ -66,3 +66,36 @@ def tiled_frames(count: int, pool: np.ndarray, start: int = 0) -> np.ndarray:
         g = start + j
         out[j] = np.roll(pool[g % p], 7 * (g // p))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# NumPy mirror of the parameter draw of the on-device generator (csrc/synth_kernel.hip): Philox4x32-10 with key
+# (seed, seed >> 32) and counter (block, g, stream id, g >> 32); stream id 1 carries the per-frame parameters.
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    m32 = 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & m32, p1 & m32, ((p0 >> 32) ^ c3 ^ k1) & m32, p0 & m32
+        k0, k1 = (k0 + 0x9E3779B9) & m32, (k1 + 0xBB67AE85) & m32
+    return c0, c1, c2, c3
+
+
+def _u01(x):
+    return np.float32((np.float32(x >> 8) + np.float32(1.0)) * np.float32(1.0 / 16777216.0))
+
+
+def device_frame_params(g: int, cfg: SonarConfig, seed: int = 1234):
+    """(delay_1, amplitude, sigma, has_second, delay_2) of frame ``g`` of ``EchoEngine.synth_frames``."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    q = _philox4x32_10(0, g & 0xFFFFFFFF, 1, (g >> 32) & 0xFFFFFFFF, k0, k1)
+    q2 = _philox4x32_10(1, g & 0xFFFFFFFF, 1, (g >> 32) & 0xFFFFFFFF, k0, k1)
+    f32 = np.float32
+    r1 = f32(1.5) + f32(12.5) * _u01(q[0])
+    amp = f32(0.05) + f32(0.35) * _u01(q[1])
+    sigma = f32(0.002) + f32(0.018) * _u01(q[2])
+    second = bool(_u01(q[3]) < f32(0.10))
+    r2 = f32(1.5) + f32(12.5) * _u01(q2[0])
+    c = f32(343.42)
+    d1 = int(np.rint(f32(2.0) * r1 / c * f32(cfg.FS)))
+    d2 = int(np.rint(f32(2.0) * r2 / c * f32(cfg.FS)))
+    return d1, float(amp), float(sigma), second, d2

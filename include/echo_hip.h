@@ -170,6 +170,14 @@ int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
 
+/* Synthetic rx frames generated in device memory (no counterpart in the reference, which records from a sound card;
+ * the result has the form AudioIO.record delivers, airSonar_optimized.py:573: int16 samples / 2**15 as float32).
+ * Frame first_frame + i is a pure function of (seed, first_frame + i): an echo of tx_mix[n_chirp] (the transmitted mix
+ * / 32768, generate_chirps :157-165) at a range drawn from U[1.5, 14] m with amplitude U[0.05, 0.4], a second echo at
+ * half amplitude in 10 % of the frames, Gaussian noise of sigma U[0.002, 0.02].  rx[B][n_rx] is written. */
+int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long long first_frame,
+                      unsigned long long seed, void* stream);
+
 /* Pipelining across batches (no counterpart in the reference).  The zero-phase IIR is a sequential recurrence that
  * leaves most of the chip idle while the other kernels of the chain are arithmetic-bound, so the IIR of the next
  * batch can run under the kernels of the current one.  echo_chain_prefetch starts it on a stream owned by the

@@ -496,3 +496,35 @@ def test_twopeak_variant_goldens_and_oracle(gold_twopeak):
     np.testing.assert_allclose(amp[0].cpu().numpy(), g["amplitude"][0], rtol=1e-12)
     assert np.array_equal(c[0].cpu().numpy(), g["stage_corr0"])
     e.close()
+
+
+def test_device_synthesised_frames(eng_default):
+    """Frames generated in device memory: on the int16 grid, a pure function of (seed, frame index) (shard
+    invariance), echo delay / amplitude / noise level as the NumPy mirror of the parameter draw says, and -- fed to
+    both sides as the same array -- chain results bit-exact against the oracle."""
+    from dsp_amd.engine import BatchedKalman
+    from dsp_amd.synth import device_frame_params
+    cfg = eng_default.cfg
+    a = eng_default.synth_frames(164, first_frame=0, seed=77)
+    b = eng_default.synth_frames(64, first_frame=100, seed=77)
+    assert torch.equal(a[100:], b)
+    assert not torch.equal(eng_default.synth_frames(8, seed=78), a[:8])
+    x = a.cpu().numpy()
+    q = x * 32768.0
+    assert np.array_equal(q, np.rint(q)) and q.min() >= -32768 and q.max() <= 32767
+    tx = eng_default.tables.tx_pcm.astype(np.float64) / 32768.0
+    for g in range(12):
+        d1, amp, sigma, second, d2 = device_frame_params(g, cfg, seed=77)
+        clean = np.zeros(cfg.n_rx)
+        for d, s in ((d1, amp),) + (((d2, 0.5 * amp),) if second else ()):
+            k = max(0, min(len(tx), cfg.n_rx - d))
+            clean[d:d + k] += s * tx[:k]
+        resid = x[g].astype(np.float64) - clean
+        assert abs(resid.std() / sigma - 1.0) < 0.08, (g, resid.std(), sigma)      # what is left is the noise
+        assert abs(resid.mean()) < 4 * sigma / np.sqrt(cfg.n_rx) + 1e-5
+    t = eng_default.tables
+    o = O.chain(x[:96], t.chirps_f32, t.filters, cfg, n_streams=8, mode="named")
+    rec, _ = eng_default.chain(a[:96].contiguous(), n_streams=8, kalman=BatchedKalman(eng_default, 8), want_spectra=False)
+    r = _rec(rec)
+    assert np.array_equal(r["peak_idx"][:, :3], o["peak_idx"])
+    np.testing.assert_allclose(r["kalman"], o["kalman"], rtol=RTOL, atol=1e-7)
