@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
                     help="internal: run the CPU oracle on one frame shard and print the seconds taken")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (exercises the "
+                         "multi-GPU code path on a one-GPU box)")
     ap.add_argument("--device-synth", action="store_true",
                     help="generate the batch in device memory (every frame distinct, no upload); the CPU baseline "
                          "then runs on frames downloaded from the device")
@@ -112,6 +115,7 @@ def main():
         print(_cpu_worker((args.cpu_worker[0], args.cpu_worker[1], 64)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or args.force_dist
     if args.gpus > 1 and "RANK" not in os.environ:
         # convenience: re-launch under torch.distributed.run as a child process (nothing has touched the GPU yet)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -131,9 +135,10 @@ def main():
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config,
            "twopeak": twopeak_config}[args.workload]()
@@ -152,9 +157,14 @@ def main():
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
     want_spec = not args.no_spectra
-    rec = torch.empty((B, 64), dtype=torch.uint8, device=dev)
+    # two record buffers: with several ranks the all-gather of step k is asynchronous and only has to be complete
+    # before step k+2 writes the same buffer again, so the collective never stalls the compute stream
+    recs = [torch.empty((B, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+    rec = recs[0]
     spec = torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
-    gathered = torch.empty((world * B, 64), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = [torch.empty((world * B, 64), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    works = [None, None]
+    counter = [0]
 
     # Steady-state pipelining: the input of step k+1 is resident, so its zero-phase IIR (a sequential recurrence that
     # leaves the arithmetic units idle) is started on the engine's own stream as soon as step k has been issued.
@@ -162,15 +172,22 @@ def main():
     pipeline = not args.no_pipeline and args.workload in ("optimized", "realtime") and B <= 16384
 
     def step():
-        eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=rec, spec_out=spec, mode=args.mode)
+        buf = counter[0] & 1
+        counter[0] += 1
+        if works[buf] is not None:
+            works[buf].wait()
+        eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
         if pipeline:
             eng.chain_prefetch(rx)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec)
+        if use_dist:
+            works[buf] = dist.all_gather_into_tensor(gathered[buf], recs[buf], async_op=True)
 
     def fence():
+        for w in works:
+            if w is not None:
+                w.wait()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -188,7 +205,7 @@ def main():
     if pipeline:
         kms["iir_wait"] = kms["iir"]           # on the caller's stream only the wait for the prefetched IIR remains
         kms["iir"] = eng.prefetch_ms()         # device time of the IIR kernel on the engine's stream
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -243,7 +260,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "optimized":
             out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds, args.cpu_workers)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        last = (counter[0] - 1) & 1
+        assert torch.equal(gathered[last][rank * B:(rank + 1) * B], recs[last])   # the gathered records hold this rank's shard
         dist.barrier()
         dist.destroy_process_group()
 

@@ -141,7 +141,12 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, dou
 
 int ensure_prefetch(EchoHandle* h, int frames) {
     if (!h->pf_stream) {
-        if (hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
+        // A high-priority stream: it gets a hardware queue of its own (streams of equal priority share a small pool of
+        // queues round-robin, and a queue shared with the caller's stream would serialise the two), and the few
+        // long-running IIR wavefronts are placed ahead of the bulk kernels they run beside.
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+        if (hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_high) != hipSuccess) return ECHO_ERR_HIP;
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&h->pf_ready[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->pf_consumed[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
