@@ -101,6 +101,53 @@ __device__ __forceinline__ void bluestein_round(int tid, const BandParams& p, un
     __syncthreads();
 }
 
+// The same with the 4608-point cyclic convolution (fft9_phases.h), 576 threads.
+__device__ __forceinline__ void bluestein9_round(int tid, const BandParams& p, unsigned char* smem) {
+    ph9_r9<false>(tid, p, smem);
+    __syncthreads();
+    ph9_r8<false>(tid, 64, p, smem);
+    __syncthreads();
+    ph9_r8<false>(tid, 8, p, smem);
+    __syncthreads();
+    ph9_mid(tid, p, smem);
+    __syncthreads();
+    ph9_r8<true>(tid, 8, p, smem);
+    __syncthreads();
+    ph9_r8<true>(tid, 64, p, smem);
+    __syncthreads();
+    ph9_r9<true>(tid, p, smem);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kF9NT) void spec9_kernel(BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    ph9_load(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    bluestein9_round(tid, p, smem);
+    ph9_store(tid, kF9NT, blk, p, smem);
+}
+
+__global__ __launch_bounds__(kF9NT) void spec9_hilbert_kernel(BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    ph9_load(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    bluestein9_round(tid, p, smem);
+    ph_hilb_mid<true>(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    bluestein9_round(tid, p, smem);
+    ph_hilb_env<true>(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_smooth(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_stats1(tid, kF9NT, p, smem);
+    __syncthreads();
+    ph_hilb_dev(tid, kF9NT, blk, p, smem);
+    __syncthreads();
+    ph_hilb_finish(tid, kF9NT, blk, p, smem);
+}
+
 // Spectrum plus the envelope branch of the band signal (hilb_phases.h): dB spectrum and signal_quality.
 __global__ __launch_bounds__(kNT, 4) void spec_hilbert_kernel(BandParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,10 +155,10 @@ __global__ __launch_bounds__(kNT, 4) void spec_hilbert_kernel(BandParams p) {
     ph_spec_load(tid, kNT, blk, p, smem);
     __syncthreads();
     bluestein_round(tid, p, smem);
-    ph_hilb_mid(tid, kNT, blk, p, smem);
+    ph_hilb_mid<false>(tid, kNT, blk, p, smem);
     __syncthreads();
     bluestein_round(tid, p, smem);
-    ph_hilb_env(tid, kNT, blk, p, smem);
+    ph_hilb_env<false>(tid, kNT, blk, p, smem);
     __syncthreads();
     ph_hilb_smooth(tid, kNT, blk, p, smem);
     __syncthreads();
@@ -130,28 +177,36 @@ extern "C" int echo_diag_read_stamps(unsigned long long* host, int n) {
 extern "C" int echo_diag_stamp_shape(int* blocks, int* slots) { *blocks = kStampBlocks; *slots = kStampSlots; return 0; }
 #endif
 
-int band_kernel_prepare(int smem_bytes, int spec_smem_bytes) {
+int band_kernel_prepare(int smem_bytes, int spec_smem_bytes, int spec_hilb_smem_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, spec_smem_bytes);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_hilbert_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec9_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, spec_smem_bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec_hilbert_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, spec_hilb_smem_bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec9_hilbert_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, spec_hilb_smem_bytes);
     return e == hipSuccess ? 0 : -4;
 }
 
 int launch_spec(const BandParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(spec_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
+    if (p.fft9) hipLaunchKernelGGL(spec9_kernel, dim3((unsigned)B * p.nb), dim3(kF9NT), p.spec_smem_bytes, s, p);
+    else hipLaunchKernelGGL(spec_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int launch_spec_hilbert(const BandParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (!p.specf_in || !p.sq_out || !p.spec_out || !p.uk || !hilb_fits(p.N, p.n2)) return -1;
-    hipLaunchKernelGGL(spec_hilbert_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_smem_bytes, s, p);
+    if (p.fft9) hipLaunchKernelGGL(spec9_hilbert_kernel, dim3((unsigned)B * p.nb), dim3(kF9NT), p.spec_hilb_smem_bytes, s, p);
+    else hipLaunchKernelGGL(spec_hilbert_kernel, dim3((unsigned)B * p.nb), dim3(kNT), p.spec_hilb_smem_bytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -90,6 +90,13 @@ struct BandParams {
     const double* specd_in;          // spectrum kernel input, float64 [B][nb][N] (or null)
     BandRes* res_out;                // [B][nb]
     const float2* uk;                // [n2+1] exp(-2*pi*i*k/N) (envelope branch of the spectrum kernel)
+    // 4608-point variant of the cyclic convolution (fft9_phases.h), used when 2*n2 - 1 <= 4608
+    int fft9;
+    const float2* f9tw9;             // [8][512]  exp(-2*pi*i*(i*m)/4608), m = 1..8
+    const float2* f9twa;             // [3][64]   W^i, W^2i, W^4i, W = exp(-2*pi*i/512)
+    const float2* f9twb;             // [3][8]    W^i, W^2i, W^4i, W = exp(-2*pi*i/64)
+    const float2* f9bhat;            // [4608]    FFT of the chirp filter / 4608, pass order
+    int spec_hilb_smem_bytes;        // LDS of the spectrum kernel with the envelope branch
     double* sq_out;                  // [B][nb] signal_quality (envelope branch; null = spectrum only)
     int write_corr_mutated;          // MODE_CORR: write the zeroed blind zone back
 };

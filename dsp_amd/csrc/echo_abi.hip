@@ -47,6 +47,7 @@ struct EchoHandle {
     // device constant tables
     double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
     float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
+    float2 *d_f9tw9 = nullptr, *d_f9twa = nullptr, *d_f9twb = nullptr, *d_f9bhat = nullptr;
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
@@ -256,7 +257,16 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         up(dev_upload(&h->d_tw, t.tw.data(), t.tw.size()));
         up(dev_upload(&h->d_post, t.post.data(), t.post.size()));
         up(dev_upload(&h->d_uk, t.uk.data(), t.uk.size()));
-        if (rc == ECHO_OK) rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes);
+        if (h->base.fft9) {
+            up(dev_upload(&h->d_f9tw9, t.f9tw9.data(), t.f9tw9.size()));
+            up(dev_upload(&h->d_f9twa, t.f9twa.data(), t.f9twa.size()));
+            up(dev_upload(&h->d_f9twb, t.f9twb.data(), t.f9twb.size()));
+            up(dev_upload(&h->d_f9bhat, t.f9bhat.data(), t.f9bhat.size()));
+        }
+        if (const char* f9 = std::getenv("ECHO_FFT9")) h->base.fft9 = h->base.fft9 && std::atoi(f9) != 0;   // development override
+        if (!h->base.fft9) h->base.spec_smem_bytes = kFftM * 8;
+        if (rc == ECHO_OK)
+            rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes, h->base.spec_hilb_smem_bytes);
     } else if (rc == ECHO_OK) {
         if (h->lbase.has_spec) {
             std::vector<cpx<float>> lr, lw, lu(h->lbase.n2 + 1);
@@ -289,6 +299,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->base.taps_rev = h->d_taps_rev; h->base.chirp = h->d_chirp;
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
     h->base.uk = h->d_uk;
+    h->base.f9tw9 = h->d_f9tw9; h->base.f9twa = h->d_f9twa; h->base.f9twb = h->d_f9twb; h->base.f9bhat = h->d_f9bhat;
     h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
@@ -300,7 +311,8 @@ void echo_destroy(EchoHandle* h) {
     if (!h) return;
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
-                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk};
+                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->pf_stream) {

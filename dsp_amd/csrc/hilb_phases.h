@@ -6,6 +6,7 @@
 // Phases of (tid, nt); plain C++ apart from the wavefront reduction.
 #pragma once
 #include "band_phases.h"
+#include "fft9_phases.h"
 
 namespace echo {
 
@@ -24,7 +25,7 @@ constexpr int kHilbMaxN = (kHilbOffSm - kHilbOffEnv) / 4;
 
 // frame sizes the layout above holds: the second transform's output (n2 elements, whole 32-element swizzle blocks)
 // must end before env[], and env[] / sm[] hold N floats each
-ECHO_HD bool hilb_fits(int N, int n2) { return ((n2 + 31) & ~31) * 8 <= kHilbOffEnv && N <= kHilbMaxN && N * 4 <= kHilbOffRed - kHilbOffSm; }
+ECHO_HD bool hilb_fits(int N, int n2) { return ((n2 + 31) & ~31) * 9 <= kHilbOffEnv && N <= kHilbMaxN && N * 4 <= kHilbOffRed - kHilbOffSm; }
 
 ECHO_HD int hilb_slots(int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -37,24 +38,28 @@ ECHO_HD HilbMisc* hilb_misc(unsigned char* smem, int nt) {
     return reinterpret_cast<HilbMisc*>(smem + kHilbOffRed + 5 * 8 * hilb_slots(nt));
 }
 
+// LDS position of element i and the cyclic length, for the 8192-point (F9 = false) and 4608-point transforms
+template <bool F9> ECHO_HD int hpos(int i) { return F9 ? pos9(i) : fa(i); }
+template <bool F9> ECHO_HD int hlen() { return F9 ? kF9M : kFftM; }
+
 // X from the first transform (dB spectrum out), V in, as the next Bluestein input a2[k] = conj(V[k]) w[k]
-ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+template <bool F9> ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
     float2* f = lds_c(smem, p.off_fft);
     const int n2 = p.n2;
     for (int k = tid; k <= n2 / 2; k += nt) {
         const float2 wk = p.bw[k];
-        const float2 zk = cmul(f[fa(k)], wk);
+        const float2 zk = cmul(f[hpos<F9>(k)], wk);
         if (k == 0) {
             float m0 = fabsf(zk.x + zk.y), m1 = fabsf(zk.x - zk.y);
             if (p.spec_db) { m0 = 20.0f * log10f(fmaxf(m0, 1e-12f)); m1 = 20.0f * log10f(fmaxf(m1, 1e-12f)); }
             p.spec_out[(size_t)blk * p.nbins] = m0;
             p.spec_out[(size_t)blk * p.nbins + n2] = m1;
-            f[fa(0)] = mk2(0.f, 0.f);
+            f[hpos<F9>(0)] = mk2(0.f, 0.f);
             continue;
         }
         const int kc = n2 - k;
         const float2 wc = p.bw[kc];
-        float2 zc = cmul(f[fa(kc)], wc); zc.y = -zc.y;                      // conj(Z[n2-k])
+        float2 zc = cmul(f[hpos<F9>(kc)], wc); zc.y = -zc.y;                      // conj(Z[n2-k])
         const float2 u = p.uk[k];                                            // exp(-2*pi*i*k/N)
         const float2 E = mk2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
         const float2 Bv = mk2(0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y));
@@ -71,20 +76,20 @@ ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const BandParams& p, unsigned
         const float2 D2 = mk2(0.5f * (Yk.x - Ycc.x), 0.5f * (Yk.y - Ycc.y));
         const float2 O2 = cmulc(D2, u);                                      // conj(u) D2
         const float2 Vk = mk2(E2.x - O2.y, E2.y + O2.x), Vc = mk2(E2.x + O2.y, -E2.y + O2.x);
-        f[fa(k)] = cmul(mk2(Vk.x, -Vk.y), wk);
-        if (kc != k) f[fa(kc)] = cmul(mk2(Vc.x, -Vc.y), wc);
+        f[hpos<F9>(k)] = cmul(mk2(Vk.x, -Vk.y), wk);
+        if (kc != k) f[hpos<F9>(kc)] = cmul(mk2(Vc.x, -Vc.y), wc);
     }
-    for (int i = n2 + tid; i < kFftM; i += nt) f[fa(i)] = mk2(0.f, 0.f);
+    for (int i = n2 + tid; i < hlen<F9>(); i += nt) f[hpos<F9>(i)] = mk2(0.f, 0.f);
 }
 
 // envelope = |x + i H(x)|: D = DFT(conj V) = c2 w; H(x)[2m] = Re D / n2, H(x)[2m+1] = -Im D / n2
-ECHO_HD void ph_hilb_env(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+template <bool F9> ECHO_HD void ph_hilb_env(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
     const float2* f = lds_c(smem, p.off_fft);
     float* env = reinterpret_cast<float*>(smem + p.off_fft + kHilbOffEnv);
     const float2* x = reinterpret_cast<const float2*>(p.specf_in + (size_t)blk * p.N);
     const float inv = 1.0f / (float)p.n2;
     for (int m = tid; m < p.n2; m += nt) {
-        const float2 d = cmul(f[fa(m)], p.bw[m]);
+        const float2 d = cmul(f[hpos<F9>(m)], p.bw[m]);
         const float2 xv = x[m];
         env[2 * m] = hypotf(xv.x, d.x * inv);
         env[2 * m + 1] = hypotf(xv.y, -d.y * inv);

@@ -7,13 +7,14 @@
 #include <vector>
 
 #include "band_phases.h"
+#include "fft9_phases.h"
 
 namespace echo {
 
 struct HostTables {
     std::vector<double> taps_rev;   // [nb][kgroups*kR]
     std::vector<double> chirp;      // [nb][mgroups*kR]
-    std::vector<float2> bw, bhat, tw, post, uk;
+    std::vector<float2> bw, bhat, tw, post, uk, f9tw9, f9twa, f9twb, f9bhat;
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -37,6 +38,27 @@ inline void fft_pow2(std::vector<std::complex<double>>& a) {
                 const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
                 a[i + k] = u + v; a[i + k + len / 2] = u - v;
             }
+    }
+}
+
+// Recursive mixed-radix FFT (factors 2 and 3), double precision, forward sign; for the one-off table of the
+// 4608-point variant.
+inline void fft_23(std::vector<std::complex<double>>& a) {
+    const size_t n = a.size();
+    if (n <= 1) return;
+    const size_t r = (n % 2 == 0) ? 2 : 3;
+    const size_t m = n / r;
+    std::vector<std::vector<std::complex<double>>> sub(r, std::vector<std::complex<double>>(m));
+    for (size_t i = 0; i < n; ++i) sub[i % r][i / r] = a[i];
+    for (size_t j = 0; j < r; ++j) fft_23(sub[j]);
+    const double pi = 3.14159265358979323846;
+    for (size_t k = 0; k < n; ++k) {
+        std::complex<double> acc(0, 0);
+        for (size_t j = 0; j < r; ++j) {
+            const double ang = -2.0 * pi * (double)((j * k) % n) / (double)n;
+            acc += sub[j][k % m] * std::complex<double>(std::cos(ang), std::sin(ang));
+        }
+        a[k] = acc;
     }
 }
 
@@ -81,7 +103,10 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.off_cchirp32 = off; off += align_up((p.mgroups + 1) * kR * 4, 16);
     p.off_misc = off; off += align_up((int)sizeof(Misc), 16);
     p.smem_bytes = off;
-    p.off_fft = 0; p.spec_smem_bytes = kFftM * 8;
+    p.off_fft = 0;
+    p.fft9 = (2 * p.n2 - 1 <= kF9M) ? 1 : 0;
+    p.spec_smem_bytes = p.fft9 ? kF9Slots * 8 : kFftM * 8;
+    p.spec_hilb_smem_bytes = kFftM * 8;                      // envelope and scratch arrays sit behind the transform
     return off <= 160 * 1024;
 }
 
@@ -137,6 +162,34 @@ inline void build_tables(HostTables& t, const BandParams& p, const double* taps,
     for (int k = 0; k <= n2; ++k) {
         const double ang = -2.0 * pi * (double)k / (double)N;
         t.uk[k] = mk(std::cos(ang), std::sin(ang));
+    }
+    if (p.fft9) {
+        // tables of the 4608-point variant
+        std::vector<std::complex<double>> b9(kF9M, std::complex<double>(0, 0));
+        b9[0] = std::conj(w[0]);
+        for (int n = 1; n < n2; ++n) { b9[n] = std::conj(w[n]); b9[kF9M - n] = std::conj(w[n]); }
+        fft_23(b9);
+        t.f9bhat.resize(kF9M);
+        for (int pos = 0; pos < kF9M; ++pos) {
+            const std::complex<double> v = b9[pass_order_freq9(pos)] / (double)kF9M;
+            t.f9bhat[pos] = mk(v.real(), v.imag());
+        }
+        t.f9tw9.resize(8 * 512);
+        for (int m = 1; m <= 8; ++m)
+            for (int i = 0; i < 512; ++i) {
+                const double ang = -2.0 * pi * (double)(i * m) / (double)kF9M;
+                t.f9tw9[(m - 1) * 512 + i] = mk(std::cos(ang), std::sin(ang));
+            }
+        auto r8 = [&](std::vector<float2>& dst, int q) {
+            dst.resize(3 * q);
+            for (int e = 0, m = 1; e < 3; ++e, m *= 2)
+                for (int i = 0; i < q; ++i) {
+                    const double ang = -2.0 * pi * (double)(i * m) / (double)(8 * q);
+                    dst[e * q + i] = mk(std::cos(ang), std::sin(ang));
+                }
+        };
+        r8(t.f9twa, 64);
+        r8(t.f9twb, 8);
     }
     t.post.resize((size_t)2 * (n2 + 1));
     for (int k = 0; k <= n2; ++k) {

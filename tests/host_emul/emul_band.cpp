@@ -185,16 +185,18 @@ extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* 
 #include "../../dsp_amd/csrc/hilb_phases.h"
 
 extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps, const double* chirps,
-                                 const float* bandf, int B, float* spec_out, double* sq_out) {
+                                 const float* bandf, int B, float* spec_out, double* sq_out, int f9) {
     BandParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_band(p, N, M, K, nb, 0, 0, 0, 6.0) || !hilb_fits(p.N, p.n2)) return -2;
     HostTables t;
     build_tables(t, p, taps, chirps);
     p.bw = t.bw.data(); p.bhat = t.bhat.data(); p.tw = t.tw.data(); p.post = t.post.data(); p.uk = t.uk.data();
+    p.f9tw9 = t.f9tw9.data(); p.f9twa = t.f9twa.data(); p.f9twb = t.f9twb.data(); p.f9bhat = t.f9bhat.data();
+    if (f9 && !p.fft9) return -2;
     p.spec_db = 1; p.specf_in = bandf; p.spec_out = spec_out; p.sq_out = sq_out;
-    const int nt = kNT;
-    std::vector<unsigned char> smem(p.spec_smem_bytes + 5 * 8 * nt + 1024);
+    const int nt = f9 ? kF9NT : kNT;
+    std::vector<unsigned char> smem(p.spec_hilb_smem_bytes + 5 * 8 * nt + 1024);
     unsigned char* s = smem.data();
 #define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
     auto round = [&]() {
@@ -210,13 +212,30 @@ extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps
         PHASE(ph_fft_r8<true>(tid, 128, p, s, tw128[tid]));
         PHASE(ph_fft_r8<true>(tid, 1024, p, s, tw1024[tid]));
     };
+    auto round9 = [&]() {
+        PHASE(ph9_r9<false>(tid, p, s));
+        PHASE(ph9_r8<false>(tid, 64, p, s));
+        PHASE(ph9_r8<false>(tid, 8, p, s));
+        PHASE(ph9_mid(tid, p, s));
+        PHASE(ph9_r8<true>(tid, 8, p, s));
+        PHASE(ph9_r8<true>(tid, 64, p, s));
+        PHASE(ph9_r9<true>(tid, p, s));
+    };
     for (int blk = 0; blk < B * nb; ++blk) {
         std::memset(s, 0xff, smem.size());
-        PHASE(ph_spec_load(tid, nt, blk, p, s));
-        round();
-        PHASE(ph_hilb_mid(tid, nt, blk, p, s));
-        round();
-        PHASE(ph_hilb_env(tid, nt, blk, p, s));
+        if (f9) {
+            PHASE(ph9_load(tid, nt, blk, p, s));
+            round9();
+            PHASE(ph_hilb_mid<true>(tid, nt, blk, p, s));
+            round9();
+            PHASE(ph_hilb_env<true>(tid, nt, blk, p, s));
+        } else {
+            PHASE(ph_spec_load(tid, nt, blk, p, s));
+            round();
+            PHASE(ph_hilb_mid<false>(tid, nt, blk, p, s));
+            round();
+            PHASE(ph_hilb_env<false>(tid, nt, blk, p, s));
+        }
         PHASE(ph_hilb_smooth(tid, nt, blk, p, s));
         PHASE(ph_hilb_stats1(tid, nt, p, s));
         PHASE(ph_hilb_dev(tid, nt, blk, p, s));
@@ -249,6 +268,37 @@ extern "C" int emul_long_spec(int N, int M, int K, int nb, const double* band, i
         int cur = 0;
         for (int ps = 0; ps < p.splan.npass; ++ps) { PHASE(ph_lspec_pass(tid, nt, p, s, ps, cur)); cur ^= 1; }
         PHASE(ph_lspec_store(tid, nt, blk, p, s, cur));
+    }
+#undef PHASE
+    return 0;
+}
+
+// 4608-point variant of the spectrum kernel (dsp_amd/csrc/fft9_phases.h).
+extern "C" int emul_spec9(int N, int M, int K, int nb, const double* taps, const double* chirps, const double* band,
+                          int B, float* spec_out) {
+    BandParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_band(p, N, M, K, nb, 0, 0, 0, 6.0) || !p.fft9) return -2;
+    HostTables t;
+    build_tables(t, p, taps, chirps);
+    p.bw = t.bw.data(); p.post = t.post.data();
+    p.f9tw9 = t.f9tw9.data(); p.f9twa = t.f9twa.data(); p.f9twb = t.f9twb.data(); p.f9bhat = t.f9bhat.data();
+    p.spec_db = 1; p.specd_in = band; p.spec_out = spec_out;
+    const int nt = kF9NT;
+    std::vector<unsigned char> smem(p.spec_smem_bytes);
+    unsigned char* s = smem.data();
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        PHASE(ph9_load(tid, nt, blk, p, s));
+        PHASE(ph9_r9<false>(tid, p, s));
+        PHASE(ph9_r8<false>(tid, 64, p, s));
+        PHASE(ph9_r8<false>(tid, 8, p, s));
+        PHASE(ph9_mid(tid, p, s));
+        PHASE(ph9_r8<true>(tid, 8, p, s));
+        PHASE(ph9_r8<true>(tid, 64, p, s));
+        PHASE(ph9_r9<true>(tid, p, s));
+        PHASE(ph9_store(tid, nt, blk, p, s));
     }
 #undef PHASE
     return 0;

@@ -178,13 +178,21 @@ def test_emulated_envelope_branch(emul, gold_default):
             assert (want, len(pk)) == (peak[f, b], npk[f, b])
             assert abs(qual - q[f, b]) <= 1e-9 and amp[f, b] == np.abs(corr[f, b]).max()
     # signal_quality from the float32 spectrum kernel with the second Bluestein round
-    emul.emul_spec_hilbert.argtypes = [I, I, I, I, P, P, P, I, P, P]
+    emul.emul_spec_hilbert.argtypes = [I, I, I, I, P, P, P, I, P, P, I]
     band = np.ascontiguousarray(g["stage_band_sig"][:4].astype(np.float32))
-    spec = np.zeros((4, nb, cfg.n_bins), np.float32); sq = np.zeros((4, nb))
     taps = np.ascontiguousarray(t.taps); chirps = np.ascontiguousarray(t.chirps)
-    assert emul.emul_spec_hilbert(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(taps), _ptr(chirps), _ptr(band), 4,
-                                  _ptr(spec), _ptr(sq)) == 0
-    np.testing.assert_allclose(sq, g["signal_quality"][g["stage_frames"][:4]], rtol=0, atol=2e-6)
-    lin, rl = 10 ** (spec.astype(np.float64) / 20), 10 ** (g["stage_spec_db"][:4].astype(np.float64) / 20)
-    live = rl.max(axis=-1) > 1e-9
+    for f9 in (0, 1):                    # 8192-point and 4608-point cyclic convolutions
+        spec = np.zeros((4, nb, cfg.n_bins), np.float32); sq = np.zeros((4, nb))
+        assert emul.emul_spec_hilbert(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(taps), _ptr(chirps), _ptr(band), 4,
+                                      _ptr(spec), _ptr(sq), f9) == 0
+        np.testing.assert_allclose(sq, g["signal_quality"][g["stage_frames"][:4]], rtol=0, atol=2e-6)
+        lin, rl = 10 ** (spec.astype(np.float64) / 20), 10 ** (g["stage_spec_db"][:4].astype(np.float64) / 20)
+        live = rl.max(axis=-1) > 1e-9
+        assert ((np.abs(lin - rl).max(axis=-1) / np.maximum(rl.max(axis=-1), 1e-300))[live] <= 1e-5).all()
+    # plain spectrum through the 4608-point variant
+    emul.emul_spec9.argtypes = [I, I, I, I, P, P, P, I, P]
+    bd = np.ascontiguousarray(g["stage_band_sig"][:4])
+    spec = np.zeros((4, nb, cfg.n_bins), np.float32)
+    assert emul.emul_spec9(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(taps), _ptr(chirps), _ptr(bd), 4, _ptr(spec)) == 0
+    lin = 10 ** (spec.astype(np.float64) / 20)
     assert ((np.abs(lin - rl).max(axis=-1) / np.maximum(rl.max(axis=-1), 1e-300))[live] <= 1e-5).all()
