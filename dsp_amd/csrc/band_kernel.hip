@@ -23,7 +23,10 @@ __global__ __launch_bounds__(kNT) void band_kernel(BandParams p) {
     STAMP(0);
     ph_load(tid, kNT, blk, p, smem);
     __syncthreads(); STAMP(1);
-    ph_fir(tid, kNT, blk, p, smem);
+    double fir_acc[kR];
+    ph_fir(tid, kNT, blk, p, smem, fir_acc);
+    __syncthreads();                          // every lane has read its FIR inputs: sig may overwrite ybuf
+    ph_fir_store(tid, kNT, blk, p, smem, fir_acc);
     __syncthreads(); STAMP(2);
     if (p.do_corr) {
         ph_corr(tid, kNT, blk, p, smem);

@@ -72,7 +72,10 @@ struct BandParams {
     int corr_fast;                   // chain only: float32 correlation where only max|corr| is needed (see ph_corr)
     // LDS carve (byte offsets, 16-B aligned)
     int off_sig, sig_len;            // double[sig_len]: band_sig at [M-1, M-1+N), zeros elsewhere
-    int off_u;                       // union: double ybuf[ybuf_len] | reduction scratch + median counts
+    int off_y;                       // double ybuf[ybuf_len]: the FIR input; shares the memory of sig (the FIR keeps its
+                                     // outputs in registers until every lane has read its inputs)
+    int off_u;                       // reduction scratch + median counts, last region of the layout
+    int smem_bytes_host;             // the host emulation keeps one reduction slot per thread instead of per wavefront
     int off_fft;                     // spectrum kernel: float2 fft[kFftM]
     int spec_smem_bytes;
     int ybuf_len, ypad;              // ybuf holds input at [ypad, ypad+N)
@@ -107,6 +110,14 @@ struct Misc {                        // lives at off_misc
 };
 
 ECHO_HD double* lds_d(unsigned char* s, int off) { return reinterpret_cast<double*>(s + off); }
+// reduction slots of a workgroup: one per wavefront on the device, one per thread in the host emulation
+ECHO_HD int red_slots(int nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return nt / 64;
+#else
+    return nt;
+#endif
+}
 ECHO_HD float2* lds_c(unsigned char* s, int off) { return reinterpret_cast<float2*>(s + off); }
 
 // One group of kR taps: acc[r] += sum_t w[(r+t)%kR] * c[t]; slot t of the register window is refilled with the
@@ -172,7 +183,7 @@ ECHO_HD void sliding_dot_f(const double* in, const float* c, int ngroups, float 
 // ---------------------------------------------------------------- phase 0: stage the input in LDS
 ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
     double* sig = lds_d(smem, p.off_sig);
-    double* yb = lds_d(smem, p.off_u);
+    double* yb = lds_d(smem, p.off_y);
     const int band = blk % p.nb, frame = blk / p.nb;
     // this band's coefficient tables -> LDS (read back as wave-uniform broadcasts by the sliding dots)
     if (p.mode == MODE_RX_FIR || p.mode == MODE_Y_FIR) {
@@ -204,8 +215,6 @@ ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned cha
             for (int k = 0; k < kBatch; ++k)
                 if (i0 + k * nt < p.ybuf_len) yb[i0 + k * nt] = v[k];
         }
-        for (int i = tid; i < p.sig_len; i += nt)
-            if (i < p.M - 1 || i >= p.M - 1 + p.N) sig[i] = 0.0;
     } else if (p.mode == MODE_BAND) {
         constexpr int kBatch = 5;
         for (int i0 = tid; i0 < p.sig_len; i0 += kBatch * nt) {
@@ -226,17 +235,17 @@ ECHO_HD void ph_load(int tid, int nt, int blk, const BandParams& p, unsigned cha
 
 // ---------------------------------------------------------------- phase 1: FIR 'same'
 // band_sig[n] = sum_j taps[j] * y[n + s - j], s = (K-1)/2  ==  sum_j' taps_rev[j'] * ybuf[n + j']
-ECHO_HD void ph_fir(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
+// Returns the lane's kR outputs in acc (kept in registers across the barrier that separates the last read of ybuf
+// from the first write of sig, which share memory).
+ECHO_HD void ph_fir(int tid, int nt, int blk, const BandParams& p, unsigned char* smem, double (&acc)[kR]) {
     if (p.mode != MODE_RX_FIR && p.mode != MODE_Y_FIR) return;
-    const double* yb = lds_d(smem, p.off_u);
-    double* sig = lds_d(smem, p.off_sig);
+    const double* yb = lds_d(smem, p.off_y);
     const int n0 = tid * kR;
     if (n0 >= p.N) return;
     // Chain fast path: band_sig[n] below nexact only reaches the float32 half of the correlation and the float32
     // spectrum, so those lanes run the FIR in float32 too (float64 is kept wherever the detector can see it).
     const int nexact = p.half + p.min_delay - (p.M - 1);
     const bool fast = p.corr_fast && p.mode == MODE_Y_FIR && !p.band_out && !p.corr_io && p.detector == 0;
-    double acc[kR];
     if (fast && n0 + kR <= nexact) {
         float accf[kR];
         sliding_dot_f(yb + n0, reinterpret_cast<const float*>(smem + p.off_ctap32), p.kgroups, accf);
@@ -245,6 +254,14 @@ ECHO_HD void ph_fir(int tid, int nt, int blk, const BandParams& p, unsigned char
     } else {
         sliding_dot(yb + n0, lds_d(smem, p.off_ctap), p.kgroups, acc);
     }
+}
+ECHO_HD void ph_fir_store(int tid, int nt, int blk, const BandParams& p, unsigned char* smem, const double (&acc)[kR]) {
+    if (p.mode != MODE_RX_FIR && p.mode != MODE_Y_FIR) return;
+    double* sig = lds_d(smem, p.off_sig);
+    for (int i = tid; i < p.sig_len; i += nt)
+        if (i < p.M - 1 || i >= p.M - 1 + p.N) sig[i] = 0.0;
+    const int n0 = tid * kR;
+    if (n0 >= p.N) return;
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
         const int n = n0 + r;
@@ -371,11 +388,7 @@ ECHO_HD void ph_corr(int tid, int nt, int blk, const BandParams& p, unsigned cha
 // phase 3: thread 0 folds the per-wavefront partials
 ECHO_HD void ph_reduce(int tid, int nt, const BandParams& p, unsigned char* smem) {
     if (!p.do_corr || tid != 0) return;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int slots = nt / 64;
-#else
-    const int slots = nt;
-#endif
+    const int slots = red_slots(nt);
     const double* red = lds_d(smem, p.off_u);
     const int* redi = reinterpret_cast<const int*>(red + 3 * slots);
     Misc* m = reinterpret_cast<Misc*>(smem + p.off_misc);
@@ -401,7 +414,7 @@ ECHO_HD void ph_rank_count(int tid, int nt, const BandParams& p, unsigned char* 
     const int n = p.noise_n;
     if (n <= 0) return;
     const float* nwf = reinterpret_cast<const float*>(lds_d(smem, p.off_nw) + n);
-    int* cnt = reinterpret_cast<int*>(lds_d(smem, p.off_u) + 4 * nt);   // [parts][n][2]
+    int* cnt = reinterpret_cast<int*>(lds_d(smem, p.off_u) + 4 * red_slots(nt));   // [parts][n][2]
     const int parts = rank_parts(nt, n);
     const int chunk = (n + parts - 1) / parts;
     for (int t = tid; t < parts * n; t += nt) {
@@ -422,7 +435,7 @@ ECHO_HD void ph_rank_count(int tid, int nt, const BandParams& p, unsigned char* 
 ECHO_HD void ph_rank_pick(int tid, int nt, const BandParams& p, unsigned char* smem) {
     if (!p.do_corr || p.detector != 0) return;
     const double* nw = lds_d(smem, p.off_nw);
-    const int* cnt = reinterpret_cast<const int*>(lds_d(smem, p.off_u) + 4 * nt);
+    const int* cnt = reinterpret_cast<const int*>(lds_d(smem, p.off_u) + 4 * red_slots(nt));
     Misc* m = reinterpret_cast<Misc*>(smem + p.off_misc);
     const int n = p.noise_n;
     if (n <= 0) { if (tid == 0) { m->med0 = 0.0; m->med1 = 0.0; } return; }

@@ -404,29 +404,33 @@ __global__ __launch_bounds__(64) void iir_filtfilt_quad_kernel(IirParams p) {
 #pragma unroll 1
     for (int t = ntail - 1; t >= 0; --t) { const double y = f.step(*bwd); yrow[t] = y; bwd -= QF; }
     if (ntail > 0) flush(nfull * CH);
-    // Full chunks.  The forward output comes back from HBM (the scratch is far larger than the caches), so each
-    // chunk's 32 rows are requested two chunks (about 3 us of arithmetic) before they are consumed: three register
-    // buffers rotate through a loop unrolled by three.
-    double bufA[CH], bufB[CH], bufC[CH];
+    // Full chunks.  The forward output comes back from HBM (the scratch is far larger than the caches), so rows are
+    // requested two half-chunks (32 samples, about 2 us of arithmetic) before they are consumed: three register
+    // buffers of 16 rows rotate through a loop unrolled by three.  Half-chunks keep the kernel at <= 184 registers,
+    // which lets it share a SIMD with two workgroups' worth of band-kernel waves when it runs as a prefetch.
+    constexpr int HB = CH / 2;
+    double bufA[HB], bufB[HB], bufC[HB];
     const double* row0 = bwd - (ptrdiff_t)(nfull * CH - 1) * QF;       // row of frame sample 0
-    auto loadc = [&](double (&buf)[CH], int c) {                        // rows of chunk c, newest first; c < 0 clamps
-        const double* top = row0 + (ptrdiff_t)((c < 0 ? 0 : c) * CH + CH - 1) * QF;
+    auto loadh = [&](double (&buf)[HB], int h) {                        // rows of half-chunk h, newest first; h < 0 clamps
+        const double* top = row0 + (ptrdiff_t)((h < 0 ? 0 : h) * HB + HB - 1) * QF;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) buf[j] = top[-(ptrdiff_t)j * QF];
+        for (int j = 0; j < HB; ++j) buf[j] = top[-(ptrdiff_t)j * QF];
     };
-    auto run = [&](const double (&buf)[CH], int c) {
+    auto runh = [&](const double (&buf)[HB], int h) {
+        double* dst = yrow + (h & 1) * HB;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) yrow[CH - 1 - j] = f.step(buf[j]);
-        flush(c * CH);
+        for (int j = 0; j < HB; ++j) dst[HB - 1 - j] = f.step(buf[j]);
+        if ((h & 1) == 0) flush((h >> 1) * CH);                         // lower half done: the 32-sample tile is complete
     };
-    if (nfull > 0) { loadc(bufA, nfull - 1); loadc(bufB, nfull - 2); }
+    const int H = 2 * nfull;
+    if (H > 0) { loadh(bufA, H - 1); loadh(bufB, H - 2); }
 #pragma unroll 1
-    for (int c = nfull - 1; c >= 0; c -= 3) {
-        loadc(bufC, c - 2); run(bufA, c);
-        if (c - 1 < 0) break;
-        loadc(bufA, c - 3); run(bufB, c - 1);
-        if (c - 2 < 0) break;
-        loadc(bufB, c - 4); run(bufC, c - 2);
+    for (int h = H - 1; h >= 0; h -= 3) {
+        loadh(bufC, h - 2); runh(bufA, h);
+        if (h - 1 < 0) break;
+        loadh(bufA, h - 3); runh(bufB, h - 1);
+        if (h - 2 < 0) break;
+        loadh(bufB, h - 4); runh(bufC, h - 2);
     }
 }
 

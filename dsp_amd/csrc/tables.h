@@ -90,19 +90,22 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.sig_len = align_up((ceil_div(p.L, kR) + p.mgroups + 1) * kR, 2);
     p.ypad = K - 1 - (K - 1) / 2;
     p.ybuf_len = align_up((ceil_div(N, kR) + p.kgroups + 1) * kR, 2);
+    // LDS layout: [sig | ybuf, sharing memory] [noise window] [coefficient tables] [misc] [reduction scratch]
     int off = 0;
-    p.off_sig = off; off += align_up(p.sig_len * 8, 16);
-    p.off_u = off;
-    int u = p.ybuf_len * 8;
-    if (u < kNT * 48) u = kNT * 48;          // reduction scratch (28 B/thread) + median counts (16 B/thread)
-    off += align_up(u, 16);
+    p.off_sig = off; p.off_y = off;
+    off += align_up((p.sig_len > p.ybuf_len ? p.sig_len : p.ybuf_len) * 8, 16);
     p.off_nw = off; off += align_up((nn > 0 ? nn : 1) * 12, 16);   // float64 window + float32 copy
     p.off_ctap = off; off += align_up((p.kgroups + 1) * kR * 8, 16);
     p.off_cchirp = off; off += align_up((p.mgroups + 1) * kR * 8, 16);
     p.off_ctap32 = off; off += align_up((p.kgroups + 1) * kR * 4, 16);
     p.off_cchirp32 = off; off += align_up((p.mgroups + 1) * kR * 4, 16);
     p.off_misc = off; off += align_up((int)sizeof(Misc), 16);
-    p.smem_bytes = off;
+    p.off_u = off;
+    // scratch: 4 doubles per reduction slot (best, amp, sumsq, index), then the median counts [parts <= 4][nn][2] ints
+    const int cnt_bytes = 4 * (nn > 0 ? nn : 1) * 2 * 4;
+    p.smem_bytes = off + align_up(4 * 8 * (kNT / 64) + cnt_bytes, 16);
+    p.smem_bytes_host = off + align_up(4 * 8 * kNT + cnt_bytes, 16);
+    off = p.smem_bytes;
     p.off_fft = 0;
     p.fft9 = (2 * p.n2 - 1 <= kF9M) ? 1 : 0;
     p.spec_smem_bytes = p.fft9 ? kF9Slots * 8 : kFftM * 8;

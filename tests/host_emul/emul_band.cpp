@@ -32,13 +32,16 @@ extern "C" int emul_band(int N, int M, int K, int nb, int min_delay, int noise_n
     std::vector<BandRes> res((size_t)B * nb);
     p.res_out = res.data();
     const int nt = kNT;
-    std::vector<unsigned char> smem(p.smem_bytes > p.spec_smem_bytes ? p.smem_bytes : p.spec_smem_bytes);
+    std::vector<unsigned char> smem(std::max(p.smem_bytes_host, std::max(p.spec_smem_bytes, kFftM * 8)));
+    struct FirAcc { double v[kR]; };
+    std::vector<FirAcc> fir(nt);
     for (int blk = 0; blk < B * nb; ++blk) {
         std::memset(smem.data(), 0xff, smem.size());   // poison: NaN patterns expose reads of unwritten LDS
         unsigned char* s = smem.data();
 #define PHASE(call) for (int tid = 0; tid < nt; ++tid) { call; }
         PHASE(ph_load(tid, nt, blk, p, s));
-        PHASE(ph_fir(tid, nt, blk, p, s));
+        PHASE(ph_fir(tid, nt, blk, p, s, fir[tid].v));
+        PHASE(ph_fir_store(tid, nt, blk, p, s, fir[tid].v));
         PHASE(ph_corr(tid, nt, blk, p, s));
         PHASE(ph_reduce(tid, nt, p, s));
         PHASE(ph_rank_count(tid, nt, p, s));
