@@ -263,6 +263,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_f9twb, t.f9twb.data(), t.f9twb.size()));
             up(dev_upload(&h->d_f9bhat, t.f9bhat.data(), t.f9bhat.size()));
         }
+        if (const char* pad = std::getenv("ECHO_BAND_SMEM_PAD")) h->base.smem_bytes += std::atoi(pad);   // development: occupancy experiments
         if (const char* f9 = std::getenv("ECHO_FFT9")) h->base.fft9 = h->base.fft9 && std::atoi(f9) != 0;   // development override
         if (!h->base.fft9) h->base.spec_smem_bytes = kFftM * 8;
         if (rc == ECHO_OK)
