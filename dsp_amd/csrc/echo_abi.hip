@@ -283,6 +283,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         }
         if (rc == ECHO_OK) rc = long_kernels_prepare(h->lbase);
     }
+    if (rc == ECHO_OK && iir_kernel_prepare() != 0) rc = ECHO_ERR_HIP;
     std::memset(&h->ebase, 0, sizeof(h->ebase));
     if (rc == ECHO_OK && !h->long_path &&
         plan_env(h->ebase, cfg->n_rx + cfg->n_chirp - 1, nb, cfg->min_delay, 5)) {

@@ -49,14 +49,31 @@ constexpr int XS = 68;      // LDS row stride (floats) of the rx tile: 64 sample
 constexpr int YS = 34;      // LDS row stride (doubles) of the output tile: 32 samples + 2 pad (16-B aligned rows)
 constexpr int CH = 32;      // samples per streamed chunk
 
+// The waves of a workgroup are independent (each owns 16 frames of one band and its own LDS tiles), so they never
+// wait for each other: only the compiler has to be kept from moving LDS accesses across the hand-over points.  A
+// wave's LDS operations execute in program order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Three independent waves per workgroup, each with its own 52,224 bytes of LDS tiles: 156,672 bytes admit one
+// workgroup per compute unit, whose waves land on different SIMDs.  (With one-wave workgroups the dispatcher stacks
+// several of these issue-bound waves on one SIMD while others stay empty.)  A 16384-frame pass of three bands is 768
+// waves = 256 workgroups, one per compute unit.
+constexpr int LW = 3;
+constexpr int kLaneWaveLds = 2 * 64 * XS * 4 + 64 * YS * 8;
+
 template <int NC, bool BODD0>
-__global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
-    __shared__ __attribute__((aligned(16))) float xt[2][64 * XS];
-    __shared__ __attribute__((aligned(16))) double yt[64 * YS];
-    const int lane = threadIdx.x;
-    // blocks id, id+8, id+16 (same XCD under round-robin placement) are the bands of one frame tile,
-    // so the three reads of an rx tile meet in one L2
-    const int id = blockIdx.x;
+__global__ __launch_bounds__(64 * LW) void iir_filtfilt_kernel(IirParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lane_lds[];
+    const int wave = threadIdx.x >> 6;
+    float (*xt)[64 * XS] = reinterpret_cast<float (*)[64 * XS]>(lane_lds + wave * kLaneWaveLds);
+    double* yt = reinterpret_cast<double*>(lane_lds + wave * kLaneWaveLds + 2 * 64 * XS * 4);
+    const int lane = threadIdx.x & 63;
+    // waves id, id+8, id+16 are the bands of one frame tile
+    const int id = blockIdx.x * LW + wave;
     const int grp = id / (8 * p.nb), rem = id % (8 * p.nb);
     const int band = rem / 8, tile = grp * 8 + rem % 8;
     if (tile >= p.ntiles) return;
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
     // ---- forward pass: left odd extension from x[0..P]
     load_chunk(0);  store_chunk(xt[0], 0);
     load_chunk(CH); store_chunk(xt[0], CH);
-    __syncthreads();
+    wave_sync();
     const float* xr = xt[0] + lane * XS;
     {
         const float x0 = xr[0];
@@ -108,11 +125,11 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
             fwd += 64;
         }
     }
-    __syncthreads();
+    wave_sync();
     // ---- forward pass: the frame itself, 32-sample chunks held in registers, next chunk prefetched
     const int nfull = N / CH, ntail = N - nfull * CH;
     load_chunk(0); store_chunk(xt[0], 0);
-    __syncthreads();
+    wave_sync();
 #pragma unroll 1
     for (int c = 0; c < nfull; ++c) {
         const int cur = c & 1;
@@ -129,18 +146,18 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
 #pragma unroll
         for (int t = 0; t < CH; ++t) { *fwd = f.step((double)xc[t], b, a); fwd += 64; }
         store_chunk(xt[cur ^ 1], 0);
-        __syncthreads();
+        wave_sync();
     }
     {
         const float* xc = xt[nfull & 1] + lane * XS;
 #pragma unroll 1
         for (int t = 0; t < ntail; ++t) { *fwd = f.step((double)xc[t], b, a); fwd += 64; }
     }
-    __syncthreads();
+    wave_sync();
     // ---- forward pass: right odd extension from x[N-64 .. N-1]
     load_chunk(N - 64); store_chunk(xt[0], 0);
     load_chunk(N - 32); store_chunk(xt[0], CH);
-    __syncthreads();
+    wave_sync();
     double ylast = 0.0;
     {
         const float xl = xr[63];
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
     double* yrow = yt + lane * YS;
     const int srow = lane >> 4, scol = (lane & 15) * 2;  // flush mapping: 4 rows x 16 double2 per instruction
     auto flush = [&](int n0) {          // write tile columns [n0, n0+32) of 64 rows as 16-byte stores
-        __syncthreads();
+        wave_sync();
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + srow;
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(64) void iir_filtfilt_kernel(IirParams p) {
                 else { dst[0] = v.x; if (n + 1 < N) dst[1] = v.y; }
             }
         }
-        __syncthreads();
+        wave_sync();
     };
     // right extension: rows NE-1 .. P+N, no output
 #pragma unroll 1
@@ -257,15 +274,6 @@ struct Df2tQuad {
 
 constexpr int QF = 16;      // frames per wave in the quad kernel
 constexpr int QW = 4;       // waves per workgroup: one per SIMD of the compute unit that receives the workgroup
-
-// The waves of a workgroup are independent (each owns 16 frames of one band and its own LDS tiles), so they never
-// wait for each other: only the compiler has to be kept from moving LDS accesses across the hand-over points.  A
-// wave's LDS operations execute in program order.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // One-wave workgroups leave the choice of SIMD to the dispatcher, which was seen to stack two or three of these
 // latency-chains on one SIMD after some predecessors (0.79 ms instead of 0.59 ms per 4096 frames); a four-wave
@@ -465,13 +473,25 @@ int launch_iir_quad(const IirParams& p, int ncoef, hipStream_t s) {
 #define IIR_INST(NC, BZ) template __global__ void iir_filtfilt_kernel<NC, BZ>(IirParams);
 IIR_INST(13, true) IIR_INST(13, false) IIR_INST(17, true) IIR_INST(17, false)
 
+// once per process and device: the lane kernel's LDS request is above the default limit
+int iir_kernel_prepare() {
+    const int smem = LW * kLaneWaveLds;
+    bool ok = true;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&iir_filtfilt_kernel<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&iir_filtfilt_kernel<13, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&iir_filtfilt_kernel<17, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&iir_filtfilt_kernel<17, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+    return ok ? 0 : -4;
+}
+
 int launch_iir(const IirParams& p, int ncoef, bool bodd0, hipStream_t s) {
     const int groups = (p.ntiles + 7) / 8;
-    dim3 grid(groups * 8 * p.nb), block(64);
-    if (ncoef == 13 && bodd0)       hipLaunchKernelGGL((iir_filtfilt_kernel<13, true>), grid, block, 0, s, p);
-    else if (ncoef == 13)           hipLaunchKernelGGL((iir_filtfilt_kernel<13, false>), grid, block, 0, s, p);
-    else if (ncoef == 17 && bodd0)  hipLaunchKernelGGL((iir_filtfilt_kernel<17, true>), grid, block, 0, s, p);
-    else if (ncoef == 17)           hipLaunchKernelGGL((iir_filtfilt_kernel<17, false>), grid, block, 0, s, p);
+    const int smem = LW * kLaneWaveLds;
+    dim3 grid((groups * 8 * p.nb + LW - 1) / LW), block(64 * LW);
+    if (ncoef == 13 && bodd0)       hipLaunchKernelGGL((iir_filtfilt_kernel<13, true>), grid, block, smem, s, p);
+    else if (ncoef == 13)           hipLaunchKernelGGL((iir_filtfilt_kernel<13, false>), grid, block, smem, s, p);
+    else if (ncoef == 17 && bodd0)  hipLaunchKernelGGL((iir_filtfilt_kernel<17, true>), grid, block, smem, s, p);
+    else if (ncoef == 17)           hipLaunchKernelGGL((iir_filtfilt_kernel<17, false>), grid, block, smem, s, p);
     else return -2;
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
