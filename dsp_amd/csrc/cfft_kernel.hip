@@ -1,0 +1,35 @@
+// Matched filter of long frames by overlap-save FFT in LDS (cfft_phases.h), float64.  Compiled with the default
+// floating-point contraction: the transform is compared at 1e-13 of the correlation's maximum, not bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "../../include/echo_hip.h"
+#include "echo_internal.h"
+#include "cfft_phases.h"
+
+namespace echo {
+
+__global__ __launch_bounds__(kCfNT) void long_corr_fft_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, pair = blockIdx.x, blk = blockIdx.y;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_CF_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, pair, blk, kCfNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+int cfft_kernel_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_fft_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kCfSmem) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
+}
+
+int launch_long_corr_fft(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int nblk = B * p.nb;
+    if (nblk > 65535 || p.k_begin < 0 || p.k_begin >= p.L || !p.cf_use || !p.cf_g || !p.cf_w2 || !p.cf_tw || p.cf_V < 1)
+        return ECHO_ERR_INVALID;
+    hipLaunchKernelGGL(long_corr_fft_kernel, dim3(cf_pairs(p), nblk), dim3(kCfNT), kCfSmem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
+}
+
+}  // namespace echo

@@ -27,6 +27,7 @@ struct EchoHandle {
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
     float2* d_uk = nullptr;
     cpx<float> *d_lroots = nullptr, *d_lwn = nullptr, *d_luk = nullptr;   // long path: spectrum FFT tables
+    cpx<double> *d_cfg = nullptr, *d_cfw2 = nullptr, *d_cftw = nullptr;   // long path: FFT matched filter tables
     // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_ready[2] = {nullptr, nullptr}, pf_consumed[2] = {nullptr, nullptr}, pf_t0 = nullptr, pf_t1 = nullptr;
@@ -65,6 +66,8 @@ struct EchoHandle {
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 5 events per slot: start, after IIR, after band, after spectrum, end
     int prof_slots = 0, prof_used = 0;
+    bool capturing = false;                // inside echo_graph_create's stream capture
+    int live_graphs = 0;                   // recorded graphs hold pointers into the scratch: it must not move while > 0
 };
 
 namespace {
@@ -75,6 +78,7 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
     return ECHO_OK;
 }
 
+// hipFree waits for the device to go idle, so work still in flight on any stream never loses its buffers here.
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
     (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf); (void)hipFree(h->d_band); (void)hipFree(h->d_pos);
@@ -88,6 +92,7 @@ void free_scratch(EchoHandle* h) {
 
 int ensure_scratch(EchoHandle* h, int frames) {
     if (frames <= h->cap_frames) return ECHO_OK;
+    if (h->live_graphs > 0) return ECHO_ERR_INVALID;       // a recorded graph still points into the current scratch
     free_scratch(h);
     const EchoConfig& c = h->cfg;
     const int P = 3 * c.iir_ncoef;
@@ -115,6 +120,7 @@ int ensure_scratch(EchoHandle* h, int frames) {
 // scratch of the full chain (raw correlation, signal quality); allocated on first use
 int ensure_full_scratch(EchoHandle* h, int frames) {
     if (frames <= h->cap_full) return ECHO_OK;
+    if (h->capturing) return ECHO_ERR_INVALID;             // nothing may be allocated inside a stream capture
     (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
     h->d_corr = nullptr; h->d_sq = nullptr; h->d_spec = nullptr; h->cap_full = 0;
     const size_t nbf = (size_t)frames * h->cfg.n_bands;
@@ -281,6 +287,16 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_luk, lu.data(), lu.size()));
             h->lbase.sroots = h->d_lroots; h->lbase.swn = h->d_lwn; h->lbase.suk = h->d_luk;
         }
+        if (const char* cf = std::getenv("ECHO_CORR_FFT")) h->lbase.cf_use = h->lbase.cf_use && std::atoi(cf) != 0;   // development override
+        if (h->lbase.cf_use) {
+            std::vector<zd> g, w2, tw;
+            cf_tables(nb, cfg->n_chirp, cfg->chirps, g, w2, tw);
+            up(dev_upload(&h->d_cfg, g.data(), g.size()));
+            up(dev_upload(&h->d_cfw2, w2.data(), w2.size()));
+            up(dev_upload(&h->d_cftw, tw.data(), tw.size()));
+            h->lbase.cf_g = h->d_cfg; h->lbase.cf_w2 = h->d_cfw2; h->lbase.cf_tw = h->d_cftw;
+            if (rc == ECHO_OK) rc = cfft_kernel_prepare();
+        }
         if (rc == ECHO_OK) rc = long_kernels_prepare(h->lbase);
     }
     if (rc == ECHO_OK && iir_kernel_prepare() != 0) rc = ECHO_ERR_HIP;
@@ -314,7 +330,7 @@ void echo_destroy(EchoHandle* h) {
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
-                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat};
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->pf_stream) {
@@ -646,7 +662,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         }
         if (prof) { (void)hipEventRecord(ev[4], s); ++h->prof_used; }
     }
-    if (h->pf_stream && h->pf_gate) {
+    if (h->pf_stream && h->pf_gate && !h->capturing) {
         h->chain_gen ^= 1;
         (void)hipEventRecord(h->chain_end[h->chain_gen], s);
         h->chain_end_set[h->chain_gen] = true;
@@ -712,6 +728,7 @@ int echo_prefetch_ms(EchoHandle* h, float* iir_ms) {
 struct EchoGraph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    EchoHandle* owner = nullptr;
 };
 
 int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
@@ -725,7 +742,9 @@ int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     h->prof = false;                        // timing events are not part of the recorded work
     h->pf_valid = false;                    // nor is a pending prefetch: the graph always runs its own IIR
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->prof = prof; return ECHO_ERR_HIP; }
+    h->capturing = true;
     rc = echo_chain(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream);
+    h->capturing = false;
     EchoGraph* g = new (std::nothrow) EchoGraph();
     const hipError_t e = hipStreamEndCapture(s, g ? &g->graph : nullptr);
     h->prof = prof;
@@ -735,6 +754,8 @@ int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         echo_graph_destroy(g);
         return ECHO_ERR_HIP;
     }
+    g->owner = h;
+    ++h->live_graphs;
     *graph = g;
     return ECHO_OK;
 }
@@ -746,6 +767,7 @@ int echo_graph_launch(EchoGraph* g, void* stream) {
 
 void echo_graph_destroy(EchoGraph* g) {
     if (!g) return;
+    if (g->owner) --g->owner->live_graphs;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

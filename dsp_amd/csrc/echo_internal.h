@@ -53,7 +53,9 @@ int launch_spec(const BandParams& p, int B, hipStream_t s);
 int launch_spec_hilbert(const BandParams& p, int B, hipStream_t s);   // spectrum + signal_quality of the band signal
 int long_kernels_prepare(const LongParams& p);
 int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <= 65535 per launch
-int launch_long_corr(const LongParams& p, int B, hipStream_t s);
+int launch_long_corr(const LongParams& p, int B, hipStream_t s);         // direct sum, or the FFT form when p.cf_use
+int cfft_kernel_prepare();
+int launch_long_corr_fft(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
 int launch_long_spec(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);

@@ -92,6 +92,7 @@ int launch_long_corr(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     const int nblk = B * p.nb;
     if (nblk > 65535 || p.k_begin < 0 || p.k_begin >= p.L) return ECHO_ERR_INVALID;
+    if (p.cf_use && p.cf_g) return launch_long_corr_fft(p, B, s);      // long chirp: overlap-save FFT
     const int tiles = (p.L - p.k_begin + kLCorrNT * kR - 1) / (kLCorrNT * kR);
     hipLaunchKernelGGL(long_corr_kernel, dim3(tiles, nblk), dim3(kLCorrNT), p.corr_smem, s, p);
     return ok();

@@ -42,6 +42,11 @@ struct LongParams {
     double* corr_out;
     int k_begin, corr_k0;
     long long corr_stride;
+    // matched filter by FFT (cfft_phases.h), chosen for long chirps
+    int cf_use, cf_V;                // cf_V: lags per sub-block = 8192 - M + 1
+    const cpx<double>* cf_g;         // [nb][8192] conj(DFT(chirp)) / 8192 in pass order
+    const cpx<double>* cf_w2;        // [4096] exp(-2 pi i n / 8192)
+    const cpx<double>* cf_tw;        // pass twiddles
     // detector: pos[q] = det_io[blk*det_stride + det_off + q], 0 <= q < L - half; q < min_delay reads as zero
     double* det_io;
     long long det_stride;
@@ -75,6 +80,9 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     if (N < 4 || M < 1 || K < 1) return false;
     p.fir_smem = (kLFirNT * kR + (p.kgroups + 1) * kR) * 8 + (p.kgroups + 1) * kR * 8;
     p.corr_smem = (N + 2 * kLPad) * 8 + (p.mgroups + 1) * kR * 8;
+    // the FFT form pays once the chirp is long: ~0.6 M multiply-adds per pair of sub-blocks against M per lag
+    p.cf_use = (M >= 512 && M <= 6144) ? 1 : 0;
+    p.cf_V = 8192 - M + 1;
     const int npos = p.L - p.half;
     p.det_smem = ((npos + 1) & ~1) * 8 + 256 * 4 + (int)sizeof(DetMisc);
     p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;

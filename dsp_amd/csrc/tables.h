@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "band_phases.h"
+#include "cfft_phases.h"
 #include "fft9_phases.h"
 
 namespace echo {
@@ -59,6 +60,37 @@ inline void fft_23(std::vector<std::complex<double>>& a) {
             acc += sub[j][k % m] * std::complex<double>(std::cos(ang), std::sin(ang));
         }
         a[k] = acc;
+    }
+}
+
+// Tables of the FFT matched filter (cfft_phases.h): g[band][e] = conj(DFT_F(chirp_band))[cf_pass_freq(e)] / F,
+// w2[n] = exp(-2 pi i n / F), and per radix-8 pass of stride q the runs W^i, W^2i, W^4i with W = exp(-2 pi i / (8q)).
+inline void cf_tables(int nb, int M, const double* chirps, std::vector<zd>& g, std::vector<zd>& w2, std::vector<zd>& tw) {
+    const double pi = 3.14159265358979323846;
+    g.assign((size_t)nb * kCfF, zmk(0, 0));
+    for (int b = 0; b < nb; ++b) {
+        std::vector<std::complex<double>> h(kCfF, std::complex<double>(0, 0));
+        for (int j = 0; j < M && j < kCfF; ++j) h[j] = chirps[(size_t)b * M + j];
+        fft_pow2(h);
+        for (int e = 0; e < kCfF; ++e) {
+            const std::complex<double> c = std::conj(h[cf_pass_freq(e)]) / (double)kCfF;
+            g[(size_t)b * kCfF + e] = zmk(c.real(), c.imag());
+        }
+    }
+    w2.resize(kCfF / 2);
+    for (int n = 0; n < kCfF / 2; ++n) {
+        const double ang = -2.0 * pi * (double)n / (double)kCfF;
+        w2[n] = zmk(std::cos(ang), std::sin(ang));
+    }
+    tw.assign(kCfTwLen, zmk(0, 0));
+    const int qs[3] = {512, 64, 8};
+    for (int qi = 0; qi < 3; ++qi) {
+        const int q = qs[qi], off = cf_tw_offset(q);
+        for (int i = 0; i < q; ++i)
+            for (int r = 0; r < 3; ++r) {
+                const double ang = -2.0 * pi * (double)(i << r) / (double)(8 * q);
+                tw[off + r * q + i] = zmk(std::cos(ang), std::sin(ang));
+            }
     }
 }
 

@@ -194,7 +194,9 @@ int echo_prefetch_ms(EchoHandle* h, float* iir_ms);
  * `stream`, which must not be the null stream; nothing executes during the capture).  echo_graph_launch replays it:
  * per tick the caller refreshes the contents of `rx` (same device buffer) and launches.  The handle's scratch is
  * reserved for B frames before the capture; B must not exceed one internal pass (16384 frames).  Other calls on the
- * handle must not run concurrently with a replay (shared scratch). */
+ * handle must not run concurrently with a replay (shared scratch).  A graph holds pointers into the handle's scratch:
+ * while one exists, a call that would have to enlarge the scratch (more frames than any call before) returns
+ * ECHO_ERR_INVALID -- size the handle with echo_reserve first -- and graphs are destroyed before their handle. */
 typedef struct EchoGraph EchoGraph;
 int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
                       double* kalman_x, double* kalman_p, uint8_t* kalman_init,

@@ -127,6 +127,32 @@ extern "C" int emul_long(int N, int M, int K, int nb, int min_delay, int detecto
     return 0;
 }
 
+// Matched filter of long frames by FFT (dsp_amd/csrc/cfft_phases.h), thread by thread: corr[k], k_begin <= k < L,
+// written to corr_out[blk * L + k].
+extern "C" int emul_long_corr_fft(int N, int M, int K, int nb, const double* chirps, const double* band, int B,
+                                  int k_begin, int nt, double* corr_out) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, 0, 1)) return -2;
+    if (!p.cf_use) return -3;
+    std::vector<zd> g, w2, tw;
+    cf_tables(nb, M, chirps, g, w2, tw);
+    p.cf_g = g.data(); p.cf_w2 = w2.data(); p.cf_tw = tw.data();
+    p.band_in = band; p.corr_out = corr_out; p.k_begin = k_begin; p.corr_k0 = 0; p.corr_stride = p.L;
+    std::vector<unsigned char> smem(kCfSmem);
+    unsigned char* s = smem.data();
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk)
+        for (int pair = 0; pair < cf_pairs(p); ++pair) {
+            std::memset(s, 0xff, smem.size());
+            ECHO_CF_SEQUENCE(PHASE, SYNC, p, s, pair, blk, nt);
+        }
+#undef PHASE
+#undef SYNC
+    return cf_pairs(p);
+}
+
 // Generic mixed-radix FFT (dsp_amd/csrc/gfft.h), thread by thread.  in/out: n interleaved (re, im) doubles.
 #include "../../dsp_amd/csrc/gfft.h"
 

@@ -302,7 +302,15 @@ def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
         assert torch.equal(got, want), tick
         assert torch.equal(g.spec, want_spec), tick
     assert torch.equal(k_direct.x, k_graph.x) and torch.equal(k_direct.p, k_graph.p)
-    g.close(); e.close()
+    # the graph points into the handle's scratch: a call that would have to enlarge it is refused while the graph lives
+    from dsp_amd._lib import EchoError
+    bigger = frames.reshape(T * S, cfg.n_rx)[:2 * S].contiguous()
+    with pytest.raises(EchoError):
+        e.chain(bigger, want_spectra=False)
+    g.close()
+    rec, _ = e.chain(bigger, want_spectra=False)
+    assert rec.shape[0] == 2 * S
+    e.close()
 
 
 def test_chain_one_million_frames_periodic_input(eng_default):

@@ -134,6 +134,36 @@ def test_emulated_long_frame_path(emul, gold_original):
     assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
 
 
+def test_emulated_fft_matched_filter(emul, gold_original):
+    """Matched filter of long frames by overlap-save FFT (cfft_phases.h), thread by thread: against the exact direct
+    sum (np.correlate in float64) for the two long-frame parameter sets, every lag and the chain's lag range, and
+    against the reference's own correlation of the golden frame."""
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_long_corr_fft.argtypes = [I, I, I, I, P, P, I, I, I, P]
+    rng = np.random.default_rng(5)
+    for N, M, k_begin, nt in ((8820, 4410, 0, 1024), (8820, 4410, 6614 + 500, 1024), (7200, 2400, 0, 256), (1000, 600, 37, 64)):
+        nb, B, L = 2, 1, N + M - 1
+        chirps = np.ascontiguousarray(rng.standard_normal((nb, M)))
+        band = np.ascontiguousarray(rng.standard_normal((B, nb, N)))
+        band[0, 1, N // 3:] *= 1e-3                                  # dynamic range inside one frame
+        corr = np.full((B, nb, L), np.nan)
+        assert emul.emul_long_corr_fft(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, nt, _ptr(corr)) > 0
+        for j in range(nb):
+            ref = np.correlate(band[0, j], chirps[j], "full")
+            assert np.isnan(corr[0, j, :k_begin]).all()             # lags below k_begin are not touched
+            assert np.abs(corr[0, j, k_begin:] - ref[k_begin:]).max() <= 2e-14 * np.abs(ref).max() * np.sqrt(M)
+    g = gold_original
+    cfg = C.original_config()
+    t = build_tables(cfg)
+    nb, N, L = cfg.n_bands, cfg.n_rx, cfg.n_corr
+    bs = np.ascontiguousarray(g["stage_band_sig0"][None])
+    chirps = np.ascontiguousarray(t.chirps)
+    corr = np.zeros((1, nb, L))
+    assert emul.emul_long_corr_fft(N, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(chirps), _ptr(bs), 1, 0, 1024, _ptr(corr)) > 0
+    ref = g["stage_corr0"]
+    assert (np.abs(corr[0] - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-7
+
+
 def test_emulated_generic_fft():
     subprocess.check_call(["make", "-C", EMUL], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(os.path.join(EMUL, "libemul.so"))
