@@ -169,7 +169,7 @@ def main():
     # Steady-state pipelining: the input of step k+1 is resident, so its zero-phase IIR (a sequential recurrence that
     # leaves the arithmetic units idle) is started on the engine's own stream as soon as step k has been issued.
     # Each step consumes one prefetched IIR and issues one, so K timed steps do the work of K full chains.
-    pipeline = not args.no_pipeline and args.workload in ("optimized", "realtime") and B <= 16384
+    pipeline = not args.no_pipeline and B <= (16384 if args.workload in ("optimized", "realtime") else 4096)
 
     def step():
         buf = counter[0] & 1

@@ -287,6 +287,8 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_luk, lu.data(), lu.size()));
             h->lbase.sroots = h->d_lroots; h->lbase.swn = h->d_lwn; h->lbase.suk = h->d_luk;
         }
+        if (const char* st = std::getenv("ECHO_DET_STAGES")) h->lbase.det_stages = std::atoi(st);   // development aids
+        if (const char* st = std::getenv("ECHO_DET_PASSES")) h->lbase.det_passes = std::atoi(st);
         if (const char* cf = std::getenv("ECHO_CORR_FFT")) h->lbase.cf_use = h->lbase.cf_use && std::atoi(cf) != 0;   // development override
         if (h->lbase.cf_use) {
             std::vector<zd> g, w2, tw;
@@ -579,7 +581,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
         // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
-        const bool pre = f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B && !h->long_path;
+        const bool pre = f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B;
         const double* y_in = h->d_y;
         if (f0 == 0) h->pf_valid = false;                  // consumed or discarded
         if (pre) {
@@ -592,7 +594,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         if (prof) (void)hipEventRecord(ev[1], s);
         if (h->long_path) {
             LongParams q = h->lbase;
-            q.fir_rx = 0; q.d_in = h->d_y; q.band_out = h->d_band;
+            q.fir_rx = 0; q.d_in = y_in; q.band_out = h->d_band;
             rc = launch_long_fir(q, n, s);
             if (rc) return rc;
             q.band_in = h->d_band; q.corr_out = h->d_pos;
@@ -696,7 +698,7 @@ int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long
 
 int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
     if (!h || !rx || B < 1) return ECHO_ERR_INVALID;
-    if (h->long_path || B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
+    if (B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
     int rc = ensure_prefetch(h, B);
     if (rc) return rc;
     const int slot = h->pf_next;

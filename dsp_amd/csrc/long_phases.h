@@ -12,16 +12,41 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ECHO_LDS_ADD(p, v) atomicAdd((p), (v))
 #define ECHO_LDS_MIN(p, v) atomicMin((p), (v))
+// hist[digit] += 1 for every active lane of the wavefront (all lanes must call).  The digits of one pass cluster
+// (sign and exponent bits are nearly the same for every element) and LDS atomics on one address are served lane by
+// lane, so digits shared by several lanes are combined into one atomic each; the peeling stops as soon as a digit
+// turns out to be shared by fewer than four lanes (spread digits go through plain atomics, which do not collide).
+__device__ __forceinline__ void wave_hist_add(int* hist, int digit, bool active) {
+    unsigned long long todo = __ballot(active);
+    const int lane = (int)__lane_id();
+    for (int it = 0; it < 8 && todo; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int d0 = __builtin_amdgcn_readlane(digit, leader);
+        const unsigned long long same = __ballot(digit == d0) & todo;
+        const int n = (int)__popcll(same);
+        if (lane == leader) atomicAdd(&hist[d0], n);
+        todo &= ~same;
+        if (n < 4) break;
+    }
+    if ((todo >> lane) & 1) atomicAdd(&hist[digit], 1);
+}
+#define ECHO_HIST_ADD(hist, digit, active) wave_hist_add((hist), (digit), (active))
+// *counter += number of lanes of the wavefront with flag set (all lanes must call): one atomic per wavefront
+#define ECHO_WAVE_COUNT_ADD(counter, flag)                                                    \
+    do { const unsigned long long b_ = __ballot(flag);                                        \
+         if (b_ && __lane_id() == 0) atomicAdd((counter), (int)__popcll(b_)); } while (0)
 #else
 #define ECHO_LDS_ADD(p, v) (*(p) += (v))
 #define ECHO_LDS_MIN(p, v) (*(p) = (v) < *(p) ? (v) : *(p))
+#define ECHO_HIST_ADD(hist, digit, active) do { if (active) (hist)[(digit)] += 1; } while (0)
+#define ECHO_WAVE_COUNT_ADD(counter, flag) do { if (flag) *(counter) += 1; } while (0)
 #endif
 
 namespace echo {
 
 constexpr int kLFirNT = 256;                   // threads per FIR workgroup: kLFirNT*kR outputs per tile
 constexpr int kLCorrNT = 768;                  // threads per correlation workgroup: kLCorrNT*kR outputs per tile
-constexpr int kLDetNT = 1024;                  // threads per detector workgroup
+constexpr int kLDetNT = 512;                   // threads per detector workgroup (1024-thread workgroups ran one per CU)
 constexpr int kLSpecNT = 512;                  // threads per spectrum workgroup
 constexpr int kLPad = 64 * kR + 2 * kR;        // zero margin either side of the LDS signal: one wavefront's spread of
                                                // first outputs (64*kR) plus the window prefetch (2*kR)
@@ -60,6 +85,7 @@ struct LongParams {
     const cpx<float>* suk;           // global: n2 + 1, exp(-2*pi*i*k/N)
     const double* spec_in;           // [B][nb][N]
     float* spec_out;                 // [B][nb][nbins]
+    int det_stages, det_passes;      // development aids: run only the first stages / passes of the detector (0 = all)
     int noise_n;                     // two-peak detector: length of the noise region of pos
     double snr_gate;
     // LDS sizes
@@ -69,7 +95,8 @@ struct LongParams {
 struct DetMisc {                     // detector scalars in LDS
     unsigned long long prefix;
     double med, mad, lo, hi;
-    int rank, shift, first, pad;
+    int rank, shift, first, cnt;     // cnt: elements left in the chosen bin
+    int nzero, pad;                  // nzero: elements equal to +0.0 (counted in the first pass)
 };
 
 inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay, int detector) {
@@ -84,7 +111,7 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.cf_use = (M >= 512 && M <= 6144) ? 1 : 0;
     p.cf_V = 8192 - M + 1;
     const int npos = p.L - p.half;
-    p.det_smem = ((npos + 1) & ~1) * 8 + 256 * 4 + (int)sizeof(DetMisc);
+    p.det_smem = ((npos + 1) & ~1) * 8 + 2 * 256 * 4 + (int)sizeof(DetMisc);
     p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;
     p.n2 = N / 2; p.nbins = N / 2 + 1;
     p.has_spec = (N % 2 == 0) && gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
@@ -201,6 +228,7 @@ ECHO_HD void ph_lcorr_run(int tid, int nt, int tile, int blk, const LongParams& 
 // ---------------------------------------------------------------- median/MAD first-crossing detector
 // Order statistics by most-significant-digit radix selection on the order-preserving integer image of a double:
 // eight passes of 8 bits, each a 256-bin LDS histogram of the elements that match the digits fixed so far.
+constexpr unsigned long long kKeyPlusZero = 0x8000000000000000ull;      // ordered_key(+0.0)
 ECHO_HD unsigned long long ordered_key(double v) {
     unsigned long long u;
     __builtin_memcpy(&u, &v, 8);
@@ -218,7 +246,7 @@ ECHO_HD int* det_hist(const LongParams& p, unsigned char* smem) {
     return reinterpret_cast<int*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
 }
 ECHO_HD DetMisc* det_misc(const LongParams& p, unsigned char* smem) {
-    return reinterpret_cast<DetMisc*>(reinterpret_cast<unsigned char*>(det_hist(p, smem)) + 256 * 4);
+    return reinterpret_cast<DetMisc*>(reinterpret_cast<unsigned char*>(det_hist(p, smem)) + 2 * 256 * 4);
 }
 
 ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
@@ -234,41 +262,104 @@ ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigne
     if (tid == 0) { DetMisc* m = det_misc(p, smem); m->first = 0x7fffffff; m->med = 0.0; m->mad = 0.0; }
 }
 
-// selection of the element of rank `rank` among key(i) = pos[i] (dev == 0) or |pos[i] - med| (dev == 1)
+// Selection of the element of rank `rank` among key(i) = pos[i] (dev == 0) or |pos[i] - med| (dev == 1): per pass a
+// 256-bin histogram of the next 8 key bits over the elements that match the bits fixed so far (two histograms in
+// turn: the idle one is cleared while the other is read), then the bin that holds the rank.  As soon as that bin
+// holds a single element the remaining bits are read off the element itself (ph_sel_find) -- for float64 data that
+// is typically after four of the eight passes.
+ECHO_HD double sel_value(const double* pos, int i, double med, int dev) { return dev ? fabs(pos[i] - med) : pos[i]; }
 ECHO_HD void ph_sel_begin(int tid, const LongParams& p, unsigned char* smem, int rank) {
+    if (tid < 512) det_hist(p, smem)[tid] = 0;
     if (tid != 0) return;
     DetMisc* m = det_misc(p, smem);
-    m->prefix = 0; m->rank = rank; m->shift = 56;
+    m->prefix = 0; m->rank = rank; m->shift = 56; m->cnt = 0; m->nzero = 0;
 }
-ECHO_HD void ph_sel_zero(int tid, const LongParams& p, unsigned char* smem) {
-    if (tid < 256) det_hist(p, smem)[tid] = 0;
-}
-ECHO_HD void ph_sel_count(int tid, int nt, const LongParams& p, unsigned char* smem, int dev) {
+ECHO_HD void ph_sel_count(int tid, int nt, const LongParams& p, unsigned char* smem, int dev, int cur) {
     const double* pos = det_pos(smem);
-    int* hist = det_hist(p, smem);
-    const DetMisc* m = det_misc(p, smem);
+    DetMisc* m = det_misc(p, smem);
+    int* hist = det_hist(p, smem) + 256 * cur;
     const int npos = p.L - p.half, shift = m->shift;
     const unsigned long long prefix = m->prefix;
     const double med = m->med;
-    for (int i = tid; i < npos; i += nt) {
-        const double v = dev ? fabs(pos[i] - med) : pos[i];
-        const unsigned long long k = ordered_key(v);
-        const bool match = shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8));
-        if (match) ECHO_LDS_ADD(&hist[(int)((k >> shift) & 255)], 1);
+    for (int i0 = 0; i0 < npos; i0 += nt) {                 // the same trip count for every lane of a wavefront
+        const int i = i0 + tid;
+        bool match = false, zero = false;
+        int digit = 0;
+        if (i < npos) {
+            const unsigned long long k = ordered_key(sel_value(pos, i, med, dev));
+            match = shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8));
+            digit = (int)((k >> shift) & 255);
+            zero = k == kKeyPlusZero;
+        }
+        ECHO_HIST_ADD(hist, digit, match);
+        if (shift == 56) ECHO_WAVE_COUNT_ADD(&m->nzero, zero);
     }
 }
-ECHO_HD void ph_sel_pick(int tid, const LongParams& p, unsigned char* smem) {
-    if (tid != 0) return;
-    const int* hist = det_hist(p, smem);
+// The blind zone puts min_delay exact zeros into pos, so the median of pos is very often 0.0: when the bin chosen in
+// the first pass holds nothing but +0.0 the selection is finished.
+ECHO_HD void sel_zero_run(DetMisc* m, int shift_before, int d, int cnt) {
+    if (shift_before == 56 && d == 0x80 && cnt == m->nzero && cnt > 0) { m->prefix = kKeyPlusZero; m->shift = -8; m->cnt = 1; }
+}
+
+// The bin that holds the rank.  Device: the first wavefront takes four bins per lane, a shuffle scan gives every
+// lane the count below its bins, and the one lane whose bins straddle the rank finishes; lanes 256..511 clear the
+// other histogram meanwhile.  Host: the same result by a serial scan.
+ECHO_HD void ph_sel_pick(int tid, const LongParams& p, unsigned char* smem, int cur) {
     DetMisc* m = det_misc(p, smem);
+    int* hist_all = det_hist(p, smem);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (tid >= 256 && tid < 512) hist_all[256 * (cur ^ 1) + (tid - 256)] = 0;
+    if (tid >= 64) return;
+    const int* hist = hist_all + 256 * cur;
+    const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    const int rank = m->rank, shift = m->shift;
+    const int sum = h0 + h1 + h2 + h3;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (tid >= off) inc += t;
+    }
+    const int exc = inc - sum;
+    if (exc <= rank && rank < inc) {                       // one lane: the rank is below the number of counted elements
+        int cum = exc, d = 4 * tid, cnt = h0;
+        if (cum + h0 <= rank) { cum += h0; ++d; cnt = h1;
+            if (cum + h1 <= rank) { cum += h1; ++d; cnt = h2;
+                if (cum + h2 <= rank) { cum += h2; ++d; cnt = h3; } } }
+        m->cnt = cnt;
+        m->rank = rank - cum;
+        m->prefix |= (unsigned long long)d << shift;
+        m->shift = shift - 8;
+        sel_zero_run(m, shift, d, cnt);
+    }
+#else
+    if (tid != 0) return;
+    const int* hist = hist_all + 256 * cur;
     int cum = 0, d = 0;
     for (; d < 255; ++d) {
         if (cum + hist[d] > m->rank) break;
         cum += hist[d];
     }
+    m->cnt = hist[d];
     m->rank -= cum;
     m->prefix |= (unsigned long long)d << m->shift;
     m->shift -= 8;
+    sel_zero_run(m, m->shift + 8, d, m->cnt);
+    for (int i = 0; i < 256; ++i) hist_all[256 * (cur ^ 1) + i] = 0;   // the histogram of the next pass
+#endif
+}
+// the chosen bin holds one element: it is the wanted one, take all of its bits
+ECHO_HD void ph_sel_find(int tid, int nt, const LongParams& p, unsigned char* smem, int dev) {
+    const double* pos = det_pos(smem);
+    DetMisc* m = det_misc(p, smem);
+    const int npos = p.L - p.half, shift = m->shift;        // bits above shift + 8 are fixed
+    if (shift < 0) return;
+    const unsigned long long prefix = m->prefix;
+    const double med = m->med;
+    for (int i = tid; i < npos; i += nt) {
+        const unsigned long long k = ordered_key(sel_value(pos, i, med, dev));
+        if ((k >> (shift + 8)) == (prefix >> (shift + 8))) m->prefix = k;      // exactly one element matches
+    }
 }
 // after the eighth pass m->prefix is the key of the wanted element
 ECHO_HD void ph_sel_store(int tid, const LongParams& p, unsigned char* smem, int which) {
@@ -396,15 +487,18 @@ ECHO_HD void ph_tp_finish(int tid, int nt, int blk, const LongParams& p, unsigne
         }                                                                                               \
         const int two_ = (npos_ % 2 == 0) ? 1 : 0;                                                      \
         PHASE(ph_ldet_load(tid, nt, blk, p, smem)) SYNC                                                 \
-        for (int dev_ = 0; dev_ < 2; ++dev_) {                                                          \
+        const int nsel_ = (p).det_stages > 0 && (p).det_stages < 3 ? (p).det_stages - 1 : 2;            \
+        const int npass_ = (p).det_passes > 0 && (p).det_passes < 8 ? (p).det_passes : 8;               \
+        for (int dev_ = 0; dev_ < nsel_; ++dev_) {                                                      \
             for (int w_ = 0; w_ <= two_; ++w_) {                                                        \
                 const int rank_ = two_ ? npos_ / 2 - 1 + w_ : npos_ / 2;                                \
                 PHASE(ph_sel_begin(tid, p, smem, rank_)) SYNC                                           \
-                for (int pass_ = 0; pass_ < 8; ++pass_) {                                               \
-                    PHASE(ph_sel_zero(tid, p, smem)) SYNC                                               \
-                    PHASE(ph_sel_count(tid, nt, p, smem, dev_)) SYNC                                    \
-                    PHASE(ph_sel_pick(tid, p, smem)) SYNC                                               \
+                for (int pass_ = 0; pass_ < npass_; ++pass_) {                                          \
+                    PHASE(ph_sel_count(tid, nt, p, smem, dev_, pass_ & 1)) SYNC                         \
+                    PHASE(ph_sel_pick(tid, p, smem, pass_ & 1)) SYNC                                    \
+                    if (det_misc(p, smem)->cnt == 1) break;                                             \
                 }                                                                                       \
+                PHASE(ph_sel_find(tid, nt, p, smem, dev_)) SYNC                                         \
                 PHASE(ph_sel_store(tid, p, smem, w_)) SYNC                                              \
             }                                                                                           \
             PHASE(if (dev_ == 0) ph_ldet_set_med(tid, p, smem, two_);                                   \

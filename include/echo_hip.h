@@ -184,7 +184,8 @@ int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long
  * handle; the next echo_chain / echo_chain_full call with the same rx and B uses the result instead of filtering
  * again (any other chain call discards it).  The caller guarantees that rx[B][N] is complete in device memory at the
  * time of the call -- the prefetch is not ordered after work on a caller stream -- and unchanged until that chain
- * call has been issued.  B must fit one internal pass (16384 frames).  echo_prefetch_ms: device time of the most
+ * call has been issued.  B must fit one internal pass (16384 frames; 4096 for the long-frame configurations),
+ * otherwise ECHO_ERR_UNSUPPORTED.  echo_prefetch_ms: device time of the most
  * recent prefetched IIR. */
 int echo_chain_prefetch(EchoHandle* h, const float* rx, int B);
 int echo_prefetch_ms(EchoHandle* h, float* iir_ms);
