@@ -40,9 +40,13 @@ __global__ __launch_bounds__(kLDetNT) void long_twopeak_kernel(LongParams p) {
     const int tid = threadIdx.x, blk = blockIdx.x;
     ph_tp_load(tid, kLDetNT, blk, p, smem);
     __syncthreads();
+    ph_tp_ref_fold(tid, kLDetNT, p, smem);
+    __syncthreads();
     ph_tp_ref(tid, kLDetNT, p, smem);
     __syncthreads();
     ph_tp_second(tid, kLDetNT, p, smem);
+    __syncthreads();
+    ph_tp_second_fold(tid, kLDetNT, p, smem);
     __syncthreads();
     ph_tp_finish(tid, kLDetNT, blk, p, smem);
 }

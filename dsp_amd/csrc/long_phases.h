@@ -432,13 +432,26 @@ ECHO_HD void ph_tp_load(int tid, int nt, int blk, const LongParams& p, unsigned 
     sc[tid] = best; sc[nt + tid] = amp; reinterpret_cast<int*>(sc + 2 * nt)[tid] = bi;
 }
 ECHO_HD void tp_better(double& b, int& i, double b2, int i2) { if (b2 > b || (b2 == b && i2 < i)) { b = b2; i = i2; } }
+// The per-thread partials are folded in two steps: 32 threads each fold a run of nt/32 entries into its first entry,
+// then thread 0 folds the 32 run heads (nt is a multiple of 32).
+constexpr int kTpFold = 32;
+ECHO_HD void ph_tp_ref_fold(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (tid >= kTpFold) return;
+    double* sc = tp_scratch(p, smem);
+    int* si = reinterpret_cast<int*>(sc + 2 * nt);
+    const int run = nt / kTpFold, t0 = tid * run;
+    double best = sc[t0], amp = sc[nt + t0]; int bi = si[t0];
+    for (int t = t0 + 1; t < t0 + run; ++t) { tp_better(best, bi, sc[t], si[t]); amp = sc[nt + t] > amp ? sc[nt + t] : amp; }
+    sc[t0] = best; sc[nt + t0] = amp; si[t0] = bi;
+}
 ECHO_HD void ph_tp_ref(int tid, int nt, const LongParams& p, unsigned char* smem) {
     if (tid != 0) return;
     const double* sc = tp_scratch(p, smem);
     const int* si = reinterpret_cast<const int*>(sc + 2 * nt);
     TpMisc* m = tp_misc(p, smem, nt);
+    const int run = nt / kTpFold;
     double best = sc[0], amp = sc[nt]; int bi = si[0];
-    for (int t = 1; t < nt; ++t) { tp_better(best, bi, sc[t], si[t]); amp = sc[nt + t] > amp ? sc[nt + t] : amp; }
+    for (int t = run; t < nt; t += run) { tp_better(best, bi, sc[t], si[t]); amp = sc[nt + t] > amp ? sc[nt + t] : amp; }
     m->best = best; m->ref = bi; m->amp = amp;
 }
 // pass 2 over pos2: argmax, any nonzero, noise power
@@ -457,13 +470,23 @@ ECHO_HD void ph_tp_second(int tid, int nt, const LongParams& p, unsigned char* s
     int* si = reinterpret_cast<int*>(sc + 2 * nt);
     sc[tid] = best; sc[nt + tid] = noise; si[tid] = (bi << 1) | nz;      // bi < 2^30
 }
+ECHO_HD void ph_tp_second_fold(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (tid >= kTpFold) return;
+    double* sc = tp_scratch(p, smem);
+    int* si = reinterpret_cast<int*>(sc + 2 * nt);
+    const int run = nt / kTpFold, t0 = tid * run;
+    double best = sc[t0], noise = sc[nt + t0]; int bi = si[t0] >> 1, nz = si[t0] & 1;
+    for (int t = t0 + 1; t < t0 + run; ++t) { tp_better(best, bi, sc[t], si[t] >> 1); noise += sc[nt + t]; nz |= si[t] & 1; }
+    sc[t0] = best; sc[nt + t0] = noise; si[t0] = (bi << 1) | nz;
+}
 ECHO_HD void ph_tp_finish(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
     if (tid != 0) return;
     const double* sc = tp_scratch(p, smem);
     const int* si = reinterpret_cast<const int*>(sc + 2 * nt);
     const TpMisc* m = tp_misc(p, smem, nt);
+    const int run = nt / kTpFold;
     double best = sc[0], noise = sc[nt]; int bi = si[0] >> 1, nz = si[0] & 1;
-    for (int t = 1; t < nt; ++t) { tp_better(best, bi, sc[t], si[t] >> 1); noise += sc[nt + t]; nz |= si[t] & 1; }
+    for (int t = run; t < nt; t += run) { tp_better(best, bi, sc[t], si[t] >> 1); noise += sc[nt + t]; nz |= si[t] & 1; }
     BandRes r;
     r.amplitude = m->amp; r.snr_db = 0.0; r.peak_idx = -1; r.pad = 0;
     const int npos = p.L - p.half;
