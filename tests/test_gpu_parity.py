@@ -282,6 +282,32 @@ def test_original_variant_goldens_and_oracle(gold_original):
     e.close()
 
 
+@pytest.mark.parametrize("which", ["original", "twopeak"])
+def test_long_matched_filter_fft_against_exact_direct_sum(which):
+    """echo_correlate of the long-frame parameter sets (overlap-save FFT in LDS, float64) against the exact direct sum
+    np.correlate(band_sig, chirp, 'full') on random band signals with a wide dynamic range inside a frame: every lag,
+    2e-14 * sqrt(M) of the correlation's maximum (the FFT path itself is ~1e-15)."""
+    cfg = C.original_config() if which == "original" else C.twopeak_config()
+    e = _engine(cfg)
+    t = build_tables(cfg)
+    rng = np.random.default_rng(11)
+    B, nb, N, M = 5, cfg.n_bands, cfg.n_rx, cfg.n_chirp
+    band = rng.standard_normal((B, nb, N))
+    band[1, :, N // 3:] *= 1e-4
+    band[2, :, : N // 2] = 0.0
+    band[3] = 0.0
+    got = e.correlate(torch.from_numpy(band).to(e.device)).cpu().numpy()
+    chirps = np.asarray(t.chirps, dtype=np.float64)
+    assert got.shape == (B, nb, N + M - 1)
+    for b in range(B):
+        for j in range(nb):
+            ref = np.correlate(band[b, j], chirps[j], "full")
+            scale = max(np.abs(ref).max(), 1e-300)
+            assert np.abs(got[b, j] - ref).max() <= 2e-14 * np.sqrt(M) * scale, (b, j)
+    assert not got[3].any()                                     # an all-zero frame correlates to exact zeros
+    e.close()
+
+
 def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
     """realtime_sonar.py streaming mode: one frame per stream per tick through a recorded HIP graph; records must be
     byte-identical to direct echo_chain calls, tick by tick, with the Kalman state carried across ticks."""
