@@ -13,6 +13,8 @@
 
 using namespace echo;
 
+constexpr int kInnerChunk = 8192;          // frames per pass when a many-pass call pipelines its own IIRs
+
 struct EchoHandle {
     EchoConfig cfg;
     int device = 0;
@@ -32,6 +34,7 @@ struct EchoHandle {
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_ready[2] = {nullptr, nullptr}, pf_consumed[2] = {nullptr, nullptr}, pf_t0 = nullptr, pf_t1 = nullptr;
     bool pf_consumed_set[2] = {false, false};
+    hipEvent_t pf_rx_ready = nullptr;               // multi-pass calls: the caller's stream at call entry
     hipEvent_t chain_end[2] = {nullptr, nullptr};   // end of the last two chain calls (alternating)
     int chain_gen = 0; bool chain_end_set[2] = {false, false};
     int pf_gate = 1;                                // 1: a prefetch starts when the chain call before the latest one has
@@ -61,6 +64,7 @@ struct EchoHandle {
     double* d_fused = nullptr;
     uint8_t* d_vany = nullptr;
     int max_chunk = 16384;                 // frames per internal pass of echo_chain
+    int inner_pipeline = 1;                // ECHO_INNER_PIPELINE=0: calls of many passes run their IIRs in line
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
@@ -134,13 +138,15 @@ int ensure_full_scratch(EchoHandle* h, int frames) {
 
 // Zero-phase IIR for B frames.  Small batches cannot fill the chip with one lane per (frame, band) (a wave is a
 // serial stream of ~370k instructions), so they run the quad-lane kernel: 4x the waves, each 1.8x shorter.
-int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, double* fwd = nullptr) {
+// corun: the IIR will run beside the arithmetic-bound kernels of another batch; from 8192 frames on the lane
+// mapping (half the instruction issue of the quad mapping) is then the better neighbour.
+int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, double* fwd = nullptr, bool corun = false) {
     IirParams p;
     p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands;
     p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     const long lane_waves = (long)p.nb * ((B + 63) / 64);
-    const bool quad = h->iir_mode == 2 || (h->iir_mode == 0 && lane_waves <= 480);   // up to ~10k frames
+    const bool quad = h->iir_mode == 2 || (h->iir_mode == 0 && lane_waves <= (corun ? 383 : 480));   // up to ~10k frames
     if (quad) { p.ntiles = (B + 15) / 16; return launch_iir_quad(p, h->cfg.iir_ncoef, s); }
     p.ntiles = (B + 63) / 64;
     return launch_iir(p, h->cfg.iir_ncoef, h->bodd0, s);
@@ -158,6 +164,7 @@ int ensure_prefetch(EchoHandle* h, int frames) {
             if (hipEventCreateWithFlags(&h->pf_ready[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->pf_consumed[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
         if (hipEventCreate(&h->pf_t0) != hipSuccess || hipEventCreate(&h->pf_t1) != hipSuccess) return ECHO_ERR_HIP;
+        if (hipEventCreateWithFlags(&h->pf_rx_ready, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&h->chain_end[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
         if (const char* g = std::getenv("ECHO_PF_GATE")) h->pf_gate = std::atoi(g);
@@ -175,6 +182,29 @@ int ensure_prefetch(EchoHandle* h, int frames) {
         hipMalloc(reinterpret_cast<void**>(&h->pf_y[1]), y_n * sizeof(double)) != hipSuccess)
         return ECHO_ERR_NOMEM;
     h->pf_cap = frames;
+    return ECHO_OK;
+}
+
+// Starts the zero-phase IIR of rx[B][N] on the handle's stream into the free one of its two output buffers.
+// after: an event the IIR must wait for (the producer of rx), or null; gate: honour the start rule of pf_gate.
+int issue_prefetch(EchoHandle* h, const float* rx, int B, hipEvent_t after, bool gate) {
+    const int slot = h->pf_next;
+    // the previous result in this slot must have been read (band kernel of the pass that consumed it)
+    if (h->pf_consumed_set[slot]) {
+        if (hipStreamWaitEvent(h->pf_stream, h->pf_consumed[slot], 0) != hipSuccess) return ECHO_ERR_HIP;
+        h->pf_consumed_set[slot] = false;
+    }
+    if (after && hipStreamWaitEvent(h->pf_stream, after, 0) != hipSuccess) return ECHO_ERR_HIP;
+    if (gate && h->pf_gate && h->chain_end_set[h->chain_gen ^ 1])
+        (void)hipStreamWaitEvent(h->pf_stream, h->chain_end[h->chain_gen ^ 1], 0);
+    (void)hipEventRecord(h->pf_t0, h->pf_stream);
+    const int rc = run_iir(h, rx, h->pf_y[slot], B, h->pf_stream, h->pf_fwd, true);
+    if (rc) return rc;
+    (void)hipEventRecord(h->pf_t1, h->pf_stream);
+    h->pf_timed = true;
+    if (hipEventRecord(h->pf_ready[slot], h->pf_stream) != hipSuccess) return ECHO_ERR_HIP;
+    h->pf_rx = rx; h->pf_B = B; h->pf_slot = slot; h->pf_valid = true;
+    h->pf_next = slot ^ 1;
     return ECHO_OK;
 }
 
@@ -226,6 +256,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (!h) return ECHO_ERR_NOMEM;
     h->cfg = *cfg;
     if (const char* m = std::getenv("ECHO_IIR_MODE")) h->iir_mode = std::atoi(m);   // development override
+    if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
     (void)hipGetDevice(&h->device);
     std::memset(&h->base, 0, sizeof(h->base));
     const bool fits = plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay,
@@ -339,7 +370,7 @@ void echo_destroy(EchoHandle* h) {
         (void)hipStreamSynchronize(h->pf_stream);
         (void)hipStreamDestroy(h->pf_stream);
         hipEvent_t evs[] = {h->pf_ready[0], h->pf_ready[1], h->pf_consumed[0], h->pf_consumed[1], h->pf_t0, h->pf_t1,
-                            h->chain_end[0], h->chain_end[1]};
+                            h->chain_end[0], h->chain_end[1], h->pf_rx_ready};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     (void)hipFree(h->pf_y[0]); (void)hipFree(h->pf_y[1]); (void)hipFree(h->pf_fwd);
@@ -568,9 +599,23 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     // frames are processed in passes of at most max_chunk; with a Kalman state each pass must hold whole
     // time steps (multiples of n_streams) so the time-major order is preserved
     int chunk = h->max_chunk;
+    // Calls of many passes pipeline themselves: passes of 8192 frames, the IIR of pass k+1 on the handle's stream
+    // beside the band kernel of pass k.  The first IIR is exposed and the co-running band kernel is slower, so this
+    // pays from about eight passes on (2.86 M against 2.76 M frames/s at a million frames).
+    const bool inner = !h->long_path && !h->capturing && h->inner_pipeline && B >= 8 * kInnerChunk &&
+                       (!kal || n_streams <= kInnerChunk);
+    if (inner) chunk = kInnerChunk;
     if (kal) {
         if (n_streams > chunk) chunk = n_streams;          // one time step per pass at least
         else chunk = (chunk / n_streams) * n_streams;
+    }
+    if (inner) {
+        int rc = ensure_prefetch(h, chunk);
+        if (rc) return rc;
+        h->pf_valid = false;                               // a pending single-batch prefetch is discarded
+        if (hipEventRecord(h->pf_rx_ready, s) != hipSuccess) return ECHO_ERR_HIP;   // rx may be produced on s
+        rc = issue_prefetch(h, rx, std::min(chunk, B), h->pf_rx_ready, false);
+        if (rc) return rc;
     }
     for (int f0 = 0; f0 < B; f0 += chunk) {
         const int n = std::min(chunk, B - f0);
@@ -581,12 +626,18 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
         // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
-        const bool pre = f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B;
+        const bool pre = inner || (f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B);
         const double* y_in = h->d_y;
-        if (f0 == 0) h->pf_valid = false;                  // consumed or discarded
+        if (f0 == 0 || inner) h->pf_valid = false;         // consumed or discarded
+        const int pre_slot = h->pf_slot;
         if (pre) {
-            if (hipStreamWaitEvent(s, h->pf_ready[h->pf_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
-            y_in = h->pf_y[h->pf_slot];
+            if (hipStreamWaitEvent(s, h->pf_ready[pre_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
+            y_in = h->pf_y[pre_slot];
+            if (inner && f0 + chunk < B) {                 // the next pass's IIR goes out before this pass's band kernel
+                rc = issue_prefetch(h, rx + (size_t)(f0 + chunk) * N, std::min(chunk, B - f0 - chunk), nullptr, false);
+                if (rc) return rc;
+                h->pf_valid = false;
+            }
         } else {
             rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
             if (rc) return rc;
@@ -627,8 +678,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             if (rc) return rc;
         }
         if (pre) {                                         // the band kernel was the last reader of the prefetched IIR output
-            if (hipEventRecord(h->pf_consumed[h->pf_slot], s) != hipSuccess) return ECHO_ERR_HIP;
-            h->pf_consumed_set[h->pf_slot] = true;
+            if (hipEventRecord(h->pf_consumed[pre_slot], s) != hipSuccess) return ECHO_ERR_HIP;
+            h->pf_consumed_set[pre_slot] = true;
         }
         if (prof) (void)hipEventRecord(ev[2], s);
         if (h->long_path) {
@@ -701,23 +752,7 @@ int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
     if (B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
     int rc = ensure_prefetch(h, B);
     if (rc) return rc;
-    const int slot = h->pf_next;
-    // the previous result in this slot must have been read (band kernel of the call that consumed it)
-    if (h->pf_consumed_set[slot]) {
-        if (hipStreamWaitEvent(h->pf_stream, h->pf_consumed[slot], 0) != hipSuccess) return ECHO_ERR_HIP;
-        h->pf_consumed_set[slot] = false;
-    }
-    if (h->pf_gate && h->chain_end_set[h->chain_gen ^ 1])
-        (void)hipStreamWaitEvent(h->pf_stream, h->chain_end[h->chain_gen ^ 1], 0);
-    (void)hipEventRecord(h->pf_t0, h->pf_stream);
-    rc = run_iir(h, rx, h->pf_y[slot], B, h->pf_stream, h->pf_fwd);
-    if (rc) return rc;
-    (void)hipEventRecord(h->pf_t1, h->pf_stream);
-    h->pf_timed = true;
-    if (hipEventRecord(h->pf_ready[slot], h->pf_stream) != hipSuccess) return ECHO_ERR_HIP;
-    h->pf_rx = rx; h->pf_B = B; h->pf_slot = slot; h->pf_valid = true;
-    h->pf_next = slot ^ 1;
-    return ECHO_OK;
+    return issue_prefetch(h, rx, B, nullptr, true);
 }
 
 int echo_prefetch_ms(EchoHandle* h, float* iir_ms) {

@@ -339,6 +339,29 @@ def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
     e.close()
 
 
+def test_many_pass_call_pipelines_itself_identically(eng_default, monkeypatch):
+    """A call of eight or more internal passes runs the IIR of pass k+1 on the handle's own stream beside the band
+    kernel of pass k (8192-frame passes); records, spectra and Kalman states must be byte-identical to the same call
+    with the in-line IIR (ECHO_INNER_PIPELINE=0, read at handle creation), ragged last pass included, twice in a row."""
+    from dsp_amd.engine import BatchedKalman
+    cfg = eng_default.cfg
+    B, S = 8 * 8192 + 4464, 16
+    pool = torch.from_numpy(synth_frames(2048, cfg, eng_default.tables.tx_pcm)).to(eng_default.device)
+    rx = pool.repeat((B + 2047) // 2048, 1)[:B].roll(3, dims=0).contiguous()
+    monkeypatch.setenv("ECHO_INNER_PIPELINE", "0")
+    plain = _engine(cfg)
+    monkeypatch.delenv("ECHO_INNER_PIPELINE")
+    k_plain, k_pipe = BatchedKalman(plain, S), BatchedKalman(eng_default, S)
+    for _ in range(2):
+        want, want_spec = plain.chain(rx, n_streams=S, kalman=k_plain, want_spectra=True)
+        got, got_spec = eng_default.chain(rx, n_streams=S, kalman=k_pipe, want_spectra=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(got_spec, want_spec)
+        assert torch.equal(k_plain.x, k_pipe.x) and torch.equal(k_plain.p, k_pipe.p)
+    plain.close()
+
+
 def test_chain_one_million_frames_periodic_input(eng_default):
     """Full size of the sharded configuration (1M frames, here on one GPU): the input repeats a 4096-frame pool, so
     every per-frame field of the records must repeat with period 4096 (internal 16384-frame passes, chunk edges and
