@@ -214,7 +214,12 @@ def main():
         frames = world * B * args.steps
         bytes_per_frame = cfg.n_rx * 4 + 60 + (cfg.n_bands * cfg.n_bins * 4 if want_spec else 0)   # 42,892 for the headline
         band_s = kms["band"] / 1e3
-        launch_frames = min(B, 16384)           # echo_chain runs batches beyond 16384 frames in passes of that size
+        # echo_chain runs batches beyond 16384 frames in passes of that size, and calls of 65536 frames or more in
+        # self-pipelined passes of 8192 (long-frame parameter sets: passes of 4096)
+        if args.workload in ("original", "twopeak"):
+            launch_frames = min(B, 4096)
+        else:
+            launch_frames = 8192 if B >= 65536 and os.environ.get("ECHO_INNER_PIPELINE", "1") != "0" else min(B, 16384)
         achieved = bytes_per_frame * launch_frames / band_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_band_kernel.json")
