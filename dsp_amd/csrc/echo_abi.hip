@@ -66,6 +66,7 @@ struct EchoHandle {
     int max_chunk = 16384;                 // frames per internal pass of echo_chain
     int inner_pipeline = 1;                // ECHO_INNER_PIPELINE=0: calls of many passes run their IIRs in line
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
+    int iir_lps = 0;                       // lanes per sequence in the quad kernel: 0 = choose, 4 or 16 (ECHO_IIR_LPS)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 5 events per slot: start, after IIR, after band, after spectrum, end
@@ -147,7 +148,14 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, dou
     p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     const long lane_waves = (long)p.nb * ((B + 63) / 64);
     const bool quad = h->iir_mode == 2 || (h->iir_mode == 0 && lane_waves <= (corun ? 383 : 480));   // up to ~10k frames
-    if (quad) { p.ntiles = (B + 15) / 16; return launch_iir_quad(p, h->cfg.iir_ncoef, s); }
+    if (quad) {
+        // a batch that leaves three quarters of the SIMDs idle in the quad mapping takes the row mapping: a quarter
+        // of the frames per wave and half the dependent chain per sample (tick latency of the streaming mode)
+        const long quad_waves = (long)p.nb * ((B + 15) / 16);
+        const int lps = h->iir_lps ? h->iir_lps : ((quad_waves <= 192 && !corun) ? 16 : 4);
+        p.ntiles = (B + 64 / lps - 1) / (64 / lps);
+        return launch_iir_quad(p, h->cfg.iir_ncoef, lps, s);
+    }
     p.ntiles = (B + 63) / 64;
     return launch_iir(p, h->cfg.iir_ncoef, h->bodd0, s);
 }
@@ -257,6 +265,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->cfg = *cfg;
     if (const char* m = std::getenv("ECHO_IIR_MODE")) h->iir_mode = std::atoi(m);   // development override
     if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
+    if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
     std::memset(&h->base, 0, sizeof(h->base));
     const bool fits = plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay,

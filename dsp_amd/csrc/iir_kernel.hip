@@ -246,6 +246,21 @@ struct Df2tQuad {
     double z[NS];
     double bl[NS], al[NS], b0;
     bool last;     // sub-lane 3: there is no state beyond its last one
+    const double* zi;
+    template <int NC> __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) {
+        b0 = p.b[band * NC];
+        last = sub == 3;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            bl[j] = p.b[band * NC + NS * sub + j + 1];
+            al[j] = p.a[band * NC + NS * sub + j + 1];
+        }
+        zi = p.zi + band * (NC - 1) + NS * sub;
+    }
+    __device__ __forceinline__ void init(double x0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) z[j] = zi[j] * x0;
+    }
     // The order of the statements is the intended issue order (the wave issues in order and a float64 result is
     // ready ~18 cycles after issue): everything that does not need this sample's y goes first, so the only exposed
     // dependences are y -> broadcast -> y*a -> subtract.  sched_barrier keeps the compiler from sinking the early
@@ -272,21 +287,80 @@ struct Df2tQuad {
     }
 };
 
-constexpr int QF = 16;      // frames per wave in the quad kernel
+// Row-wide variant for small batches (streaming ticks): one state per lane, a sequence per DPP row of 16 lanes
+// (lanes beyond the 2*order states carry zero coefficients and stay zero), so a wave owns 4 frames and a sample costs
+// ~13 instructions instead of ~27: the tick latency, which is the length of this dependent chain, drops accordingly.
+// row_shl:1 with bound_ctrl hands every lane its neighbour's state and the last lane a zero; row_newbcast:0 spreads y.
+// Four times the instruction issue per frame of the quad mapping: only for batches that leave the chip idle anyway.
+__device__ __forceinline__ double dpp_row_bcast0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150, 0xf, 0xf, false);   // row_newbcast:0 (every lane is written)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_row_next(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x101, 0xf, 0xf, true);    // row_shl:1, out-of-row reads give 0
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x101, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NC>
+struct Df2tRow {
+    double z, bl, al, b0;
+    const double* zi;
+    bool live;
+    __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) {
+        live = sub < NC - 1;
+        const int k = live ? sub : 0;
+        b0 = p.b[band * NC];
+        bl = live ? p.b[band * NC + k + 1] : 0.0;
+        al = live ? p.a[band * NC + k + 1] : 0.0;
+        zi = p.zi + band * (NC - 1) + k;
+    }
+    __device__ __forceinline__ void init(double x0) { z = live ? zi[0] * x0 : 0.0; }
+    // a sample is ~15 instructions of 4+ cycles each on the 16-lane SIMD: the wave is bound by its own issue, so the
+    // count of instructions is what matters here, not the length of the dependent chain
+    __device__ __forceinline__ double step(double x) {
+        const double yb = b0 * x;
+        const double px = x * bl;
+        const double zn = dpp_row_next(z);
+        const double yc = z + yb;
+        const double t = zn + px;
+        __builtin_amdgcn_sched_barrier(0);
+        const double y = dpp_row_bcast0(yc);
+        const double py = y * al;
+        z = t - py;
+        __builtin_amdgcn_sched_barrier(0);
+        return y;
+    }
+};
+
 constexpr int QW = 4;       // waves per workgroup: one per SIMD of the compute unit that receives the workgroup
 
 // One-wave workgroups leave the choice of SIMD to the dispatcher, which was seen to stack two or three of these
 // latency-chains on one SIMD after some predecessors (0.79 ms instead of 0.59 ms per 4096 frames); a four-wave
 // workgroup is spread over the four SIMDs of its compute unit.
-template <int NC>
+template <int NC, int LPS> struct IirFilt;
+template <int NC> struct IirFilt<NC, 4> {
+    Df2tQuad<(NC - 1) / 4> f;
+    __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) { f.template setup<NC>(p, band, sub); }
+};
+template <int NC> struct IirFilt<NC, 16> {
+    Df2tRow<NC> f;
+    __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) { f.setup(p, band, sub); }
+};
+
+// LPS lanes per (frame, band): 4 (quad mapping, 16 frames per wave) or 16 (row mapping, 4 frames per wave)
+template <int NC, int LPS>
 __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p) {
-    constexpr int NS = (NC - 1) / 4;
+    constexpr int QF = 64 / LPS;                // frames per wave
     __shared__ __attribute__((aligned(16))) float xt_all[QW][2][QF * XS];
     __shared__ __attribute__((aligned(16))) double yt_all[QW][QF * YS];
     const int wave = threadIdx.x >> 6;
     float (*xt)[QF * XS] = xt_all[wave];
     double* yt = yt_all[wave];
-    const int lane = threadIdx.x & 63, u = lane >> 2, sub = lane & 3;
+    const int lane = threadIdx.x & 63, u = lane / LPS, sub = lane % LPS;
     const int id = blockIdx.x * QW + wave;
     const int grp = id / (8 * p.nb), rem = id % (8 * p.nb);
     const int band = rem / 8, tile = grp * 8 + rem % 8;
@@ -294,19 +368,10 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     const int N = p.N, P = p.P, NE = N + 2 * P;
     const int f0 = tile * QF;
 
-    Df2tQuad<NS> f;
-    f.b0 = p.b[band * NC];
-    f.last = sub == 3;
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        f.bl[j] = p.b[band * NC + NS * sub + j + 1];
-        f.al[j] = p.a[band * NC + NS * sub + j + 1];
-    }
-    const double* zi = p.zi + band * (NC - 1) + NS * sub;
-    auto init = [&](double x0) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) f.z[j] = zi[j] * x0;
-    };
+    IirFilt<NC, LPS> filt;
+    filt.setup(p, band, sub);
+    auto& f = filt.f;
+    auto init = [&](double x0) { f.init(x0); };
 
     // cooperative load of columns [c0, c0+32) of the 16 rows: lane -> (row it*2 + lane/32, column lane%32)
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -458,14 +523,19 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     }
 }
 
-template __global__ void iir_filtfilt_quad_kernel<13>(IirParams);
-template __global__ void iir_filtfilt_quad_kernel<17>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<13, 4>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<17, 4>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<13, 16>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<17, 16>(IirParams);
 
-int launch_iir_quad(const IirParams& p, int ncoef, hipStream_t s) {
+// p.ntiles = ceil(B / (64 / lps)) tiles of 64 / lps frames; lps = 4 or 16
+int launch_iir_quad(const IirParams& p, int ncoef, int lps, hipStream_t s) {
     const int groups = (p.ntiles + 7) / 8;
     dim3 grid(groups * 8 * p.nb / QW), block(64 * QW);
-    if (ncoef == 13)      hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13>), grid, block, 0, s, p);
-    else if (ncoef == 17) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17>), grid, block, 0, s, p);
+    if (ncoef == 13 && lps == 4)       hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13, 4>), grid, block, 0, s, p);
+    else if (ncoef == 17 && lps == 4)  hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17, 4>), grid, block, 0, s, p);
+    else if (ncoef == 13 && lps == 16) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13, 16>), grid, block, 0, s, p);
+    else if (ncoef == 17 && lps == 16) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17, 16>), grid, block, 0, s, p);
     else return -2;
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
