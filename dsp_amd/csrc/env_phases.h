@@ -53,8 +53,8 @@ struct EnvParams {
 };
 
 struct EnvMisc {
-    double sum_sm, max_sm, min_sm, sum_x, sum_x2, amp, sum_noise;     // round 1
-    double ss_sm, ss_x, ss_d;                                          // round 2
+    double sum_sm, max_sm, min_sm, sum_x, sum_x2, amp, sum_noise;     // first statistics pass
+    double ss_sm, ss_x, ss_d;                                          // second statistics pass
     double mean_sm, mean_x, mean_d, std_sm, thr;
     double best_val;
     int undecided, best_idx, n_final, n_cand;
@@ -275,7 +275,7 @@ ECHO_HD void ph_env_part1_final(int tid, int nt, const EnvParams& p, unsigned ch
     m->mean_x = m->sum_x / (double)p.L;
     m->mean_d = p.L > 1 ? (sm[p.L - 1] - sm[0]) / (double)(p.L - 1) : 0.0;
 }
-// round 2: squared deviations (np.std is the two-pass population deviation)
+// second pass: squared deviations (np.std is the two-pass population deviation)
 ECHO_HD void ph_env_part2(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     double* scratch = reinterpret_cast<double*>(env_buf(smem, p, sm_buf ^ 1));

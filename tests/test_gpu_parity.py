@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the reference-generated golden vectors and
 against the CPU oracle on identical synthetic frames.
 
-Tolerances (BASELINE north_star): peak indices and band validity bit-exact; distances, SNR and
+Tolerances (north_star of BASELINE.json): peak indices and band validity bit-exact; distances, SNR and
 confidences within 1e-4 relative (they are stored as float32 in the result record); spectra within
 1e-4 of the frame's spectral peak on linear magnitude (|dX| / max|X| <= 1e-4) -- a dB comparison is
 only meaningful near the pass band because stop-band bins sit ~200 dB down, below float32 resolution --
@@ -121,7 +121,7 @@ def test_fir_bank_is_convolve_same(gold_default, eng_default):
 
 
 def test_chain_4096_frames_bit_exact_peaks_vs_oracle(eng_default):
-    """BASELINE config 2: 4096 synthetic frames on one GPU, full chain, peak indices bit-exact vs NumPy/SciPy."""
+    """BASELINE.json configs[1]: 4096 synthetic frames on one GPU, full chain, peak indices bit-exact vs NumPy/SciPy."""
     cfg = eng_default.cfg
     t = eng_default.tables
     B = 4096
