@@ -137,6 +137,23 @@ def test_chain_4096_frames_bit_exact_peaks_vs_oracle(eng_default):
     assert exp["valid"].sum() > 0.9 * exp["valid"].size
 
 
+@pytest.mark.parametrize("bands", [((6000.0, 10000.0),), ((4000.0, 8000.0), (12000.0, 16000.0))])
+def test_chain_with_one_and_two_bands_vs_oracle(bands):
+    """len(BANDS) other than three (the reference iterates over whatever BANDS holds, airSonar_optimized.py:703-720):
+    kernel grids, record layout and fusion over one and two bands, named and full chain, against the oracle."""
+    cfg = C.optimized_config(bands)
+    e = _engine(cfg)
+    t = e.tables
+    nb = cfg.n_bands
+    rx = synth_frames(96, cfg, t.tx_pcm, start=4242)
+    for mode in ("named", "full"):
+        rec, spec = e.chain(rx, mode=mode)
+        exp = O.chain(rx, t.chirps_f32, t.filters, cfg, mode=mode, keep=("spec_db",))
+        check_records(_rec(rec), exp, nb=nb)
+        check_spectra(spec.cpu().numpy(), exp["spec_db"])
+    e.close()
+
+
 def test_chain_is_shard_invariant(eng_default):
     """Rows [a, b) of a full-batch run equal a run over frames [a, b) alone, bit for bit (multi-GPU sharding)."""
     cfg = eng_default.cfg
