@@ -109,7 +109,7 @@ int ensure_scratch(EchoHandle* h, int frames) {
         (!h->long_path && hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess) ||
         (h->long_path && (hipMalloc(reinterpret_cast<void**>(&h->d_band), y_n * sizeof(double)) != hipSuccess ||
                           hipMalloc(reinterpret_cast<void**>(&h->d_pos), (size_t)frames * c.n_bands *
-                                    (size_t)(c.detector == ECHO_DET_TWOPEAK ? h->lbase.L : h->lbase.L - h->lbase.half) *
+                                    (size_t)(c.detector != ECHO_DET_MAD ? h->lbase.L : h->lbase.L - h->lbase.half) *
                                     sizeof(double)) != hipSuccess)) ||
         hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
@@ -229,7 +229,7 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
 
 bool detector_supported(const EchoHandle* h) {
     const int d = h->cfg.detector;
-    return h->long_path ? (d == ECHO_DET_MAD || d == ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
+    return h->long_path ? (d >= ECHO_DET_MEDIAN && d <= ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
 }
 
 }  // namespace
@@ -279,6 +279,13 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         }
         h->max_chunk = std::min(4096, 65535 / cfg->n_bands);
         h->lbase.noise_n = cfg->noise_n; h->lbase.snr_gate = cfg->snr_gate_db;
+        {   // the noise window as NumPy's slices truncate it (airSonar_optimized.py:209, realtime_sonar.py:134)
+            const int npos = h->lbase.L - h->lbase.half;
+            int nn = cfg->noise_n;
+            if (cfg->detector == ECHO_DET_MEDIAN && cfg->min_delay + nn > npos) nn = npos > cfg->min_delay ? npos - cfg->min_delay : 0;
+            if (cfg->detector == ECHO_DET_MEANPOW && nn > npos) nn = npos;
+            if (cfg->detector == ECHO_DET_MEDIAN || cfg->detector == ECHO_DET_MEANPOW) h->lbase.noise_n = nn;
+        }
     }
     const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
     h->bodd0 = true;
@@ -658,7 +665,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_long_fir(q, n, s);
             if (rc) return rc;
             q.band_in = h->d_band; q.corr_out = h->d_pos;
-            const bool all_lags = q.detector == ECHO_DET_TWOPEAK;       // its amplitude is max|corr| over every lag
+            const bool all_lags = q.detector != ECHO_DET_MAD;           // every other detector reports max|corr| over all lags
             q.k_begin = all_lags ? 0 : std::min(q.half + q.min_delay, q.L - 1);
             q.corr_k0 = all_lags ? 0 : q.half; q.corr_stride = all_lags ? q.L : q.L - q.half;
             rc = launch_long_corr(q, n, s);

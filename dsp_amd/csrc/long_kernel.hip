@@ -51,6 +51,16 @@ __global__ __launch_bounds__(kLDetNT) void long_twopeak_kernel(LongParams p) {
     ph_tp_finish(tid, kLDetNT, blk, p, smem);
 }
 
+__global__ __launch_bounds__(kLDetNT) void long_median_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_LMED_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kLDetNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
 __global__ __launch_bounds__(kLSpecNT) void long_spec_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
@@ -76,6 +86,8 @@ int long_kernels_prepare(const LongParams& p) {
                             p.det_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(long_twopeak_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             p.tp_smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(long_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.lm_smem) != hipSuccess ||
         (p.has_spec && hipFuncSetAttribute(reinterpret_cast<const void*>(long_spec_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.spec_smem) != hipSuccess))
         return ECHO_ERR_HIP;
@@ -113,6 +125,10 @@ int launch_long_detect(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (p.detector == ECHO_DET_TWOPEAK) {
         hipLaunchKernelGGL(long_twopeak_kernel, dim3(B * p.nb), dim3(kLDetNT), p.tp_smem, s, p);
+        return ok();
+    }
+    if (p.detector == ECHO_DET_MEDIAN || p.detector == ECHO_DET_MEANPOW) {
+        hipLaunchKernelGGL(long_median_kernel, dim3(B * p.nb), dim3(kLDetNT), p.lm_smem, s, p);
         return ok();
     }
     hipLaunchKernelGGL(long_detect_kernel, dim3(B * p.nb), dim3(kLDetNT), p.det_smem, s, p);

@@ -89,7 +89,7 @@ struct LongParams {
     int noise_n;                     // two-peak detector: length of the noise region of pos
     double snr_gate;
     // LDS sizes
-    int fir_smem, corr_smem, det_smem, spec_smem, tp_smem;
+    int fir_smem, corr_smem, det_smem, spec_smem, tp_smem, lm_smem;
 };
 
 struct DetMisc {                     // detector scalars in LDS
@@ -113,11 +113,13 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     const int npos = p.L - p.half;
     p.det_smem = ((npos + 1) & ~1) * 8 + 2 * 256 * 4 + (int)sizeof(DetMisc);
     p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;
+    p.lm_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + kLDetNT * 4 + 64;
     p.n2 = N / 2; p.nbins = N / 2 + 1;
     p.has_spec = (N % 2 == 0) && gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
     p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
     if (p.spec_smem > 160 * 1024) p.has_spec = 0;
-    return p.fir_smem <= 160 * 1024 && p.corr_smem <= 160 * 1024 && p.det_smem <= 160 * 1024;
+    return p.fir_smem <= 160 * 1024 && p.corr_smem <= 160 * 1024 && p.det_smem <= 160 * 1024 &&
+           p.lm_smem <= 160 * 1024;
 }
 
 // ---------------------------------------------------------------- spectrum of a long frame
@@ -497,6 +499,105 @@ ECHO_HD void ph_tp_finish(int tid, int nt, int blk, const LongParams& p, unsigne
     }
     if (p.res_out) p.res_out[blk] = r;
 }
+
+// ---------------------------------------------------------------- median / mean-power detector on long frames
+// first_strong_peak of airSonar_optimized.py:200-219 (noise floor = median(|pos[min_delay : min_delay + n]|)^2) and of
+// realtime_sonar.py:127-142 (mean(pos[:n]^2)) for frames that do not fit the single-workgroup kernel of
+// band_phases.h; same results as ph_corr .. ph_finish there.  det_io points at the whole correlation (L lags):
+// amplitude = max|corr| after the blind zone has been zeroed.  p.noise_n is the window length after NumPy's slice
+// truncation.  LDS: double pos[npos], scratch double best[nt], amp[nt], sumsq[nt], int idx[nt], then LmMisc.
+struct LmMisc { double best, amp, sumsq, med0, med1; int bidx, pad; };
+ECHO_HD double* lm_scratch(const LongParams& p, unsigned char* smem) {
+    return reinterpret_cast<double*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
+}
+ECHO_HD LmMisc* lm_misc(const LongParams& p, unsigned char* smem, int nt) {
+    return reinterpret_cast<LmMisc*>(reinterpret_cast<unsigned char*>(lm_scratch(p, smem) + 3 * nt) + nt * 4);
+}
+ECHO_HD void ph_lm_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    double* pos = det_pos(smem);
+    double* corr = p.det_io + (size_t)blk * p.det_stride;
+    double best = -INFINITY, amp = 0.0, sumsq = 0.0;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < p.L; k += nt) {
+        double v = corr[k];
+        if (k >= p.half) {
+            const int q = k - p.half;
+            if (q < p.min_delay) { v = 0.0; if (p.write_mutated) corr[k] = 0.0; }
+            pos[q] = v;
+            if (v > best) { best = v; bi = q; }                 // ascending q per thread: the first index wins ties
+            if (p.detector == 2 && q < p.noise_n) sumsq += v * v;
+        }
+        const double av = fabs(v);
+        amp = av > amp ? av : amp;
+    }
+    double* sc = lm_scratch(p, smem);
+    sc[tid] = best; sc[nt + tid] = amp; sc[2 * nt + tid] = sumsq; reinterpret_cast<int*>(sc + 3 * nt)[tid] = bi;
+}
+ECHO_HD void ph_lm_fold(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (tid >= kTpFold) return;
+    double* sc = lm_scratch(p, smem);
+    int* si = reinterpret_cast<int*>(sc + 3 * nt);
+    const int run = nt / kTpFold, t0 = tid * run;
+    double best = sc[t0], amp = sc[nt + t0], ss = sc[2 * nt + t0]; int bi = si[t0];
+    for (int t = t0 + 1; t < t0 + run; ++t) {
+        tp_better(best, bi, sc[t], si[t]);
+        amp = sc[nt + t] > amp ? sc[nt + t] : amp;
+        ss += sc[2 * nt + t];
+    }
+    sc[t0] = best; sc[nt + t0] = amp; sc[2 * nt + t0] = ss; si[t0] = bi;
+}
+ECHO_HD void ph_lm_best(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (tid != 0) return;
+    const double* sc = lm_scratch(p, smem);
+    const int* si = reinterpret_cast<const int*>(sc + 3 * nt);
+    LmMisc* m = lm_misc(p, smem, nt);
+    const int run = nt / kTpFold;
+    double best = sc[0], amp = sc[nt], ss = sc[2 * nt]; int bi = si[0];
+    for (int t = run; t < nt; t += run) {
+        tp_better(best, bi, sc[t], si[t]);
+        amp = sc[nt + t] > amp ? sc[nt + t] : amp;
+        ss += sc[2 * nt + t];
+    }
+    m->best = best; m->bidx = bi; m->amp = amp; m->sumsq = ss; m->med0 = 0.0; m->med1 = 0.0;
+}
+// np.median of the noise window: element v is the k-th order statistic iff #(u < v) <= k < #(u < v) + #(u == v)
+ECHO_HD void ph_lm_median(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    if (p.detector != 0) return;
+    const double* nw = det_pos(smem) + p.min_delay;
+    LmMisc* m = lm_misc(p, smem, nt);
+    const int n = p.noise_n;
+    const int k0 = (n - 1) / 2, k1 = n / 2;
+    for (int i = tid; i < n; i += nt) {
+        const double v = fabs(nw[i]);
+        int less = 0, eq = 0;
+        for (int j = 0; j < n; ++j) { const double u = fabs(nw[j]); less += (u < v) ? 1 : 0; eq += (u == v) ? 1 : 0; }
+        if (less <= k0 && k0 < less + eq) m->med0 = v;
+        if (less <= k1 && k1 < less + eq) m->med1 = v;
+    }
+}
+ECHO_HD void ph_lm_finish(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    if (tid != 0 || !p.res_out) return;
+    const LmMisc* m = lm_misc(p, smem, nt);
+    BandRes r;
+    r.amplitude = m->amp; r.pad = 0;
+    const int npos = p.L - p.half;
+    if (npos <= p.min_delay) { r.peak_idx = -1; r.snr_db = 0.0; p.res_out[blk] = r; return; }
+    double noise_floor;
+    if (p.detector == 0) { const double med = (m->med0 + m->med1) / 2.0; noise_floor = med * med; }
+    else                 { noise_floor = m->sumsq / (double)p.noise_n; }
+    const double peak_power = m->best * m->best;
+    double snr = 0.0;
+    if (noise_floor > 0.0) snr = 10.0 * log10(peak_power / noise_floor);
+    if (snr < p.snr_gate) { r.peak_idx = -1; r.snr_db = 0.0; }
+    else                  { r.peak_idx = m->bidx; r.snr_db = snr; }
+    p.res_out[blk] = r;
+}
+#define ECHO_LMED_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)              \
+    PHASE(ph_lm_load(tid, nt, blk, p, smem)) SYNC                       \
+    PHASE(ph_lm_fold(tid, nt, p, smem)) SYNC                            \
+    PHASE(ph_lm_best(tid, nt, p, smem)) SYNC                            \
+    PHASE(ph_lm_median(tid, nt, p, smem)) SYNC                          \
+    PHASE(ph_lm_finish(tid, nt, blk, p, smem))
 
 // The barrier-separated sequence of one detector workgroup; SYNC is __syncthreads() on the device and the end of a
 // for-all-threads loop on the host.

@@ -154,6 +154,36 @@ def test_chain_with_one_and_two_bands_vs_oracle(bands):
     e.close()
 
 
+@pytest.mark.parametrize("kind,listen,chirp", [("optimized", 0.1, None), ("optimized", 0.06, 0.004),
+                                               ("optimized", 0.098, 0.008), ("optimized", 0.2, 0.05),
+                                               ("realtime", 0.12, None)])
+def test_chain_with_other_frame_lengths_vs_oracle(kind, listen, chirp):
+    """Frame and chirp lengths other than the default ones (the reference derives them from R_MAX, R_MIN and the
+    temperature, airSonar_optimized.py:93-103): N = 4800 takes the 8192-point spectrum kernel instead of the
+    4608-point one, N = 2880 / M = 192 and N = 4704 / M = 384 move every tile and tap boundary.  Correlations longer
+    than one workgroup holds (N = 4800, 4704; N = 9600 / M = 2400, whose matched filter is the FFT one; N = 5760 with
+    realtime_sonar.py's mean-power detector) take the tiled long-frame kernels with the median / mean-power detector.
+    Named chain against the oracle; the full chain too where the envelope branch supports the correlation length."""
+    from dsp_amd._lib import EchoError
+    from dataclasses import replace
+    base = C.optimized_config(C.BANDS_DISTINCT) if kind == "optimized" else C.realtime_config()
+    cfg = replace(base, LISTEN_LEN_FIXED=listen, CHIRP_LEN_FIXED=chirp)
+    e = _engine(cfg)
+    t = e.tables
+    rx = synth_frames(80, cfg, t.tx_pcm, start=99)
+    rec, spec = e.chain(rx)
+    exp = O.chain(rx, t.chirps_f32, t.filters, cfg, mode="named", keep=("spec_db",))
+    check_records(_rec(rec), exp)
+    check_spectra(spec.cpu().numpy(), exp["spec_db"])
+    try:
+        rec_full, _ = e.chain(rx, mode="full")
+    except EchoError:
+        rec_full = None                                  # correlation length the envelope branch does not take
+    if rec_full is not None:
+        check_records(_rec(rec_full), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="full"))
+    e.close()
+
+
 def test_chain_is_shard_invariant(eng_default):
     """Rows [a, b) of a full-batch run equal a run over frames [a, b) alone, bit for bit (multi-GPU sharding)."""
     cfg = eng_default.cfg
