@@ -93,7 +93,7 @@ typedef struct EchoHandle EchoHandle;
 
 /* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
  * (airSonar_optimized.py:598-619).  Uses the current HIP device.
- * Sizes: n_rx even.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
+ * Sizes: the spectra need an even n_rx (odd frame lengths run everything else).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
  * ECHO_ERR_UNSUPPORTED from echo_create: IIR order other than 6 or 8 (iir_ncoef 13 / 17), or a frame so long that one

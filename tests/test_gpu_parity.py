@@ -184,6 +184,23 @@ def test_chain_with_other_frame_lengths_vs_oracle(kind, listen, chirp):
     e.close()
 
 
+def test_chain_with_odd_frame_length_without_spectra():
+    """An odd number of samples per frame (N = 4795): the spectrum kernels need an even N and refuse, everything else
+    of the chain runs (tiled kernels) and matches the oracle."""
+    from dsp_amd._lib import EchoError
+    from dataclasses import replace
+    cfg = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=0.0999)
+    assert cfg.n_rx % 2 == 1
+    e = _engine(cfg)
+    t = e.tables
+    rx = synth_frames(40, cfg, t.tx_pcm, start=5)
+    rec, _ = e.chain(rx, want_spectra=False)
+    check_records(_rec(rec), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="named"))
+    with pytest.raises(EchoError):
+        e.chain(rx, want_spectra=True)
+    e.close()
+
+
 def test_chain_is_shard_invariant(eng_default):
     """Rows [a, b) of a full-batch run equal a run over frames [a, b) alone, bit for bit (multi-GPU sharding)."""
     cfg = eng_default.cfg
