@@ -127,6 +127,49 @@ extern "C" int emul_long(int N, int M, int K, int nb, int min_delay, int detecto
     return 0;
 }
 
+// Detectors of the long-frame path on given correlations corr[B*nb][L] (whole correlation, mutated like a direct
+// first_strong_peak call where the reference mutates): detector 0 median, 1 MAD, 2 mean power, 3 two-peak.
+extern "C" int emul_long_detect(int N, int M, int K, int nb, int min_delay, int detector, int noise_n, double gate,
+                                double* corr, int B, int* peak, double* snr, double* amp, int* valid) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, min_delay, detector)) return -2;
+    const int npos = p.L - p.half;
+    int nn = noise_n;
+    if (detector == 0 && min_delay + nn > npos) nn = npos > min_delay ? npos - min_delay : 0;
+    if (detector == 2 && nn > npos) nn = npos;
+    p.noise_n = nn; p.snr_gate = gate;
+    std::vector<BandRes> res((size_t)B * nb);
+    p.res_out = res.data();
+    p.det_io = corr; p.det_stride = p.L; p.det_off = p.half; p.write_mutated = 1;
+    std::vector<unsigned char> smem(std::max(p.det_smem, std::max(p.tp_smem, p.lm_smem)));
+    unsigned char* s = smem.data();
+    const int nt = kLDetNT;
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        if (detector == 1) {
+            ECHO_LDET_SEQUENCE(PHASE, SYNC, p, s, blk, nt);
+        } else if (detector == 3) {
+            PHASE(ph_tp_load(tid, nt, blk, p, s));
+            PHASE(ph_tp_ref_fold(tid, nt, p, s));
+            PHASE(ph_tp_ref(tid, nt, p, s));
+            PHASE(ph_tp_second(tid, nt, p, s));
+            PHASE(ph_tp_second_fold(tid, nt, p, s));
+            PHASE(ph_tp_finish(tid, nt, blk, p, s));
+        } else {
+            ECHO_LMED_SEQUENCE(PHASE, SYNC, p, s, blk, nt);
+        }
+    }
+#undef PHASE
+#undef SYNC
+    for (size_t i = 0; i < res.size(); ++i) {
+        peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude; valid[i] = res[i].pad;
+    }
+    return 0;
+}
+
 // Matched filter of long frames by FFT (dsp_amd/csrc/cfft_phases.h), thread by thread: corr[k], k_begin <= k < L,
 // written to corr_out[blk * L + k].
 extern "C" int emul_long_corr_fft(int N, int M, int K, int nb, const double* chirps, const double* band, int B,

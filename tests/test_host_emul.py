@@ -134,6 +134,62 @@ def test_emulated_long_frame_path(emul, gold_original):
     assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
 
 
+def test_emulated_long_frame_detectors_against_oracle(emul):
+    """The four detectors of the tiled long-frame path, thread by thread, on synthetic correlations (noise, one or two
+    peaks, silence, ties, a peak inside the blind zone) against the oracle's first_strong_peak functions: indices
+    exact, SNR to 1e-12, and the in-place blind-zone zeroing."""
+    from oracle import echo_oracle as O
+    P, I, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    emul.emul_long_detect.argtypes = [I, I, I, I, I, I, I, D, P, I, P, P, P, P]
+    rng = np.random.default_rng(3)
+    N, M, nb, B = 5200, 400, 2, 6
+    L = N + M - 1
+    half = L // 2
+    npos = L - half
+    fs = 48000
+
+    def make():
+        c = rng.standard_normal((B, nb, L)) * 1e-3
+        c[0, 0, half + 900] = 0.5                                  # one clear echo
+        c[0, 1, half + 100] = 2.0; c[0, 1, half + 1500] = 0.3      # strongest sample inside the blind zone
+        c[1, 0, half + 700] = 0.4; c[1, 0, half + 1900] = 0.4      # tie: first index wins
+        c[1, 1] = 0.0                                              # silence
+        c[2, 0, : half] *= 500.0                                   # amplitude dominated by the first half
+        c[2, 1, half + npos - 1] = 1.0                             # peak at the last lag
+        return c
+
+    for det, min_delay, noise_n in ((0, 331, 240), (0, 2300, 240), (2, 164, int(npos * 0.2)), (1, 500, 0), (3, 0, int(npos * 0.2))):
+        c = make()
+        ref_c = c.copy()
+        peak = np.zeros((B, nb), np.int32); snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); valid = np.zeros((B, nb), np.int32)
+        assert emul.emul_long_detect(N, M, 101, nb, min_delay, det, noise_n, 6.0, _ptr(c), B, _ptr(peak), _ptr(snr),
+                                     _ptr(amp), _ptr(valid)) == 0
+        for b in range(B):
+            for j in range(nb):
+                r = ref_c[b, j]
+                if det == 0:
+                    class Cfg: SNR_NOISE_MS = noise_n / fs; CHIRP_LEN = 0.0
+                    want, want_snr = O.first_strong_peak(r, fs, Cfg, min_delay)
+                elif det == 2:
+                    class Cfg: CHIRP_LEN = 0.0
+                    want, want_snr = O.first_strong_peak_meanpow(r, fs, Cfg, min_delay)
+                elif det == 1:
+                    want, want_snr = O.first_strong_peak_mad(r, fs, min_delay), 0.0
+                else:
+                    want, want_snr = O.first_strong_peak_twopeak(r, fs)
+                if det == 3:
+                    assert bool(valid[b, j]) == (want is not None), (det, b, j)
+                    if want is not None:
+                        assert peak[b, j] == want, (det, b, j)
+                else:
+                    assert peak[b, j] == (-1 if want is None else want), (det, min_delay, b, j, peak[b, j], want)
+                if det != 1:
+                    np.testing.assert_allclose(snr[b, j], want_snr, rtol=1e-12, atol=1e-12)
+                    np.testing.assert_allclose(amp[b, j], np.abs(r).max(), rtol=0, atol=0)
+                if det != 3:
+                    assert np.array_equal(c[b, j], r), (det, b, j)       # same in-place mutation as the reference's
+
+
 def test_emulated_fft_matched_filter(emul, gold_original):
     """Matched filter of long frames by overlap-save FFT (cfft_phases.h), thread by thread: against the exact direct
     sum (np.correlate in float64) for the two long-frame parameter sets, every lag and the chain's lag range, and
