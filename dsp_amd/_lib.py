@@ -16,7 +16,7 @@ EXPORTS = [
     "echo_fir_bank", "echo_bandpass_bank", "echo_spectrum", "echo_mag2db", "echo_correlate",
     "echo_first_strong_peak", "echo_envelope_detection", "echo_argmax", "echo_confidence_fuse", "echo_kalman_update",
     "echo_synth_frames", "echo_chain", "echo_chain_full", "echo_chain_prefetch", "echo_prefetch_ms", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
-    "echo_set_profiling", "echo_last_kernel_ms",
+    "echo_set_profiling", "echo_last_kernel_ms", "echo_chain_noalloc", "echo_noalloc_max_frames",
 ]
 
 
@@ -64,6 +64,8 @@ def load():
     lib.echo_confidence_fuse.argtypes = [P, P, P, P, P, I, P]
     lib.echo_kalman_update.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.echo_chain_noalloc.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.echo_noalloc_max_frames.argtypes = [P]
     lib.echo_chain_full.argtypes = [P, P, P, P, P, P, P, P, I, I, P]
     lib.echo_synth_frames.argtypes = [P, P, P, I, C.c_longlong, C.c_ulonglong, P]
     lib.echo_chain_prefetch.argtypes = [P, P, I]

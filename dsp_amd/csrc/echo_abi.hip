@@ -15,6 +15,27 @@ using namespace echo;
 
 constexpr int kInnerChunk = 8192;          // frames per pass when a many-pass call pipelines its own IIRs
 
+// Device scratch of one internal pass of the chain: everything beyond the caller's inputs and outputs.
+struct Scratch {
+    double* fwd = nullptr;                 // IIR forward-pass output
+    double* y = nullptr;                   // IIR result
+    float* bandf = nullptr;                // float32 band_sig handed from the band kernel to the spectrum kernel
+    double* band = nullptr;                // long path: band_sig
+    double* pos = nullptr;                 // long path: corr[half:] (or every lag)
+    BandRes* res = nullptr;
+    double* fused = nullptr;
+    uint8_t* vany = nullptr;
+    EnvRes* env = nullptr;                 // envelope-branch results, [frames][nb]
+};
+
+// Scratch of echo_chain_noalloc: one array per GPU (every device that loads the library holds its own copy at its own
+// address until the process ends).  Host code never uses the array's name as an address: echo_create asks the runtime
+// for the device address once per device and the entry point carves that pointer.
+constexpr size_t kNoallocBytes = (size_t)ECHO_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char* g_noalloc_ptr[kMaxDevices];          // per device: device address of `scratch`, null until looked up
+
 struct EchoHandle {
     EchoConfig cfg;
     int device = 0;
@@ -23,7 +44,6 @@ struct EchoHandle {
     bool has_env = false;                  // envelope branch available (even correlation length with small prime factors)
     EnvParams ebase;
     cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr;
-    EnvRes* d_env = nullptr;               // envelope-branch results, [frames][nb]
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
@@ -55,14 +75,8 @@ struct EchoHandle {
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
-    double* d_fwd = nullptr;               // IIR forward-pass output
-    double* d_y = nullptr;                 // IIR result
-    float* d_bandf = nullptr;              // float32 band_sig handed from the band kernel to the spectrum kernel
-    double* d_band = nullptr;              // long path: band_sig
-    double* d_pos = nullptr;               // long path: corr[half:]
-    BandRes* d_res = nullptr;
-    double* d_fused = nullptr;
-    uint8_t* d_vany = nullptr;
+    Scratch sc;                            // allocated by ensure_scratch
+    unsigned char* noalloc = nullptr;      // device address of this device's static scratch array (echo_chain_noalloc)
     int max_chunk = 16384;                 // frames per internal pass of echo_chain
     int inner_pipeline = 1;                // ECHO_INNER_PIPELINE=0: calls of many passes run their IIRs in line
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
@@ -85,36 +99,66 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 
 // hipFree waits for the device to go idle, so work still in flight on any stream never loses its buffers here.
 void free_scratch(EchoHandle* h) {
-    (void)hipFree(h->d_fwd); (void)hipFree(h->d_y); (void)hipFree(h->d_res); (void)hipFree(h->d_fused);
-    (void)hipFree(h->d_vany); (void)hipFree(h->d_bandf); (void)hipFree(h->d_band); (void)hipFree(h->d_pos);
-    (void)hipFree(h->d_env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
-    h->d_spec = nullptr;
-    h->d_bandf = nullptr; h->d_band = h->d_pos = nullptr; h->d_env = nullptr; h->d_corr = nullptr; h->d_sq = nullptr;
+    (void)hipFree(h->sc.fwd); (void)hipFree(h->sc.y); (void)hipFree(h->sc.res); (void)hipFree(h->sc.fused);
+    (void)hipFree(h->sc.vany); (void)hipFree(h->sc.bandf); (void)hipFree(h->sc.band); (void)hipFree(h->sc.pos);
+    (void)hipFree(h->sc.env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
+    h->sc = Scratch();
+    h->d_corr = nullptr; h->d_sq = nullptr; h->d_spec = nullptr;
     h->cap_full = 0;
-    h->d_fwd = h->d_y = nullptr; h->d_res = nullptr; h->d_fused = nullptr; h->d_vany = nullptr;
     h->cap_frames = 0;
+}
+
+// Elements per frame-batch of each scratch buffer (shared by the allocating and the carving path).
+struct ScratchSizes { size_t fwd, y, bandf, band, pos, res, fused, vany, env; };
+ScratchSizes scratch_sizes(const EchoHandle* h, int frames) {
+    const EchoConfig& c = h->cfg;
+    const int P = 3 * c.iir_ncoef;
+    const size_t ntiles = (size_t)(frames + 63) / 64;
+    ScratchSizes z;
+    z.fwd = (size_t)c.n_bands * ntiles * (size_t)(c.n_rx + 2 * P) * 64 * sizeof(double);
+    z.y = (size_t)frames * c.n_bands * c.n_rx * sizeof(double);
+    z.bandf = h->long_path ? 0 : (size_t)frames * c.n_bands * c.n_rx * sizeof(float);
+    z.band = h->long_path ? z.y : 0;
+    z.pos = h->long_path ? (size_t)frames * c.n_bands *
+                           (size_t)(c.detector != ECHO_DET_MAD ? h->lbase.L : h->lbase.L - h->lbase.half) * sizeof(double) : 0;
+    z.res = (size_t)frames * c.n_bands * sizeof(BandRes);
+    z.fused = (size_t)frames * sizeof(double);
+    z.vany = (size_t)frames;
+    z.env = (size_t)frames * c.n_bands * sizeof(EnvRes);
+    return z;
+}
+
+// Carves one pass's scratch out of a caller-provided device region; false when `bytes` is too small.
+bool carve_scratch(const EchoHandle* h, int frames, unsigned char* base, size_t bytes, Scratch& sc) {
+    const ScratchSizes z = scratch_sizes(h, frames);
+    size_t off = 0;
+    auto take = [&](size_t n) -> unsigned char* {
+        if (n == 0) return nullptr;
+        unsigned char* p = base + off;
+        off += (n + 255) & ~(size_t)255;
+        return p;
+    };
+    sc.fwd = reinterpret_cast<double*>(take(z.fwd));
+    sc.y = reinterpret_cast<double*>(take(z.y));
+    sc.bandf = reinterpret_cast<float*>(take(z.bandf));
+    sc.band = reinterpret_cast<double*>(take(z.band));
+    sc.pos = reinterpret_cast<double*>(take(z.pos));
+    sc.res = reinterpret_cast<BandRes*>(take(z.res));
+    sc.fused = reinterpret_cast<double*>(take(z.fused));
+    sc.vany = reinterpret_cast<uint8_t*>(take(z.vany));
+    sc.env = reinterpret_cast<EnvRes*>(take(z.env));
+    return off <= bytes;
 }
 
 int ensure_scratch(EchoHandle* h, int frames) {
     if (frames <= h->cap_frames) return ECHO_OK;
     if (h->live_graphs > 0) return ECHO_ERR_INVALID;       // a recorded graph still points into the current scratch
     free_scratch(h);
-    const EchoConfig& c = h->cfg;
-    const int P = 3 * c.iir_ncoef;
-    const size_t ntiles = (size_t)(frames + 63) / 64;
-    const size_t fwd_n = (size_t)c.n_bands * ntiles * (size_t)(c.n_rx + 2 * P) * 64;
-    const size_t y_n = (size_t)frames * c.n_bands * c.n_rx;
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_fwd), fwd_n * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_y), y_n * sizeof(double)) != hipSuccess ||
-        (!h->long_path && hipMalloc(reinterpret_cast<void**>(&h->d_bandf), y_n * sizeof(float)) != hipSuccess) ||
-        (h->long_path && (hipMalloc(reinterpret_cast<void**>(&h->d_band), y_n * sizeof(double)) != hipSuccess ||
-                          hipMalloc(reinterpret_cast<void**>(&h->d_pos), (size_t)frames * c.n_bands *
-                                    (size_t)(c.detector != ECHO_DET_MAD ? h->lbase.L : h->lbase.L - h->lbase.half) *
-                                    sizeof(double)) != hipSuccess)) ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_res), (size_t)frames * c.n_bands * sizeof(BandRes)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_fused), (size_t)frames * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_env), (size_t)frames * c.n_bands * sizeof(EnvRes)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->d_vany), (size_t)frames) != hipSuccess) {
+    const ScratchSizes z = scratch_sizes(h, frames);
+    auto get = [](auto** p, size_t n) { return n == 0 || hipMalloc(reinterpret_cast<void**>(p), n) == hipSuccess; };
+    if (!get(&h->sc.fwd, z.fwd) || !get(&h->sc.y, z.y) || !get(&h->sc.bandf, z.bandf) || !get(&h->sc.band, z.band) ||
+        !get(&h->sc.pos, z.pos) || !get(&h->sc.res, z.res) || !get(&h->sc.fused, z.fused) ||
+        !get(&h->sc.env, z.env) || !get(&h->sc.vany, z.vany)) {
         free_scratch(h);
         return ECHO_ERR_NOMEM;
     }
@@ -143,7 +187,7 @@ int ensure_full_scratch(EchoHandle* h, int frames) {
 // mapping (half the instruction issue of the quad mapping) is then the better neighbour.
 int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, double* fwd = nullptr, bool corun = false) {
     IirParams p;
-    p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->d_fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
+    p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->sc.fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands;
     p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     const long lane_waves = (long)p.nb * ((B + 63) / 64);
@@ -246,6 +290,7 @@ const char* echo_strerror(int code) {
         case ECHO_ERR_NOMEM: return "device allocation failed";
         case ECHO_ERR_HIP: return "HIP runtime call or kernel launch failed";
         case ECHO_ERR_NODEVICE: return "no HIP device";
+        case ECHO_ERR_TOO_LARGE: return "batch exceeds the fixed scratch of the entry point that allocates nothing";
         default: return "unknown error";
     }
 }
@@ -267,6 +312,17 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
+    // device address of this GPU's copy of the static scratch array, looked up once per device
+    if (h->device < 0 || h->device >= kMaxDevices) { delete h; return ECHO_ERR_UNSUPPORTED; }
+    if (!g_noalloc_ptr[h->device]) {
+        unsigned char* ptr = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)) != hipSuccess || !ptr) {
+            delete h;
+            return ECHO_ERR_HIP;
+        }
+        g_noalloc_ptr[h->device] = ptr;
+    }
+    h->noalloc = g_noalloc_ptr[h->device];
     std::memset(&h->base, 0, sizeof(h->base));
     const bool fits = plan_band(h->base, cfg->n_rx, cfg->n_chirp, cfg->n_taps, cfg->n_bands, cfg->min_delay,
                                 cfg->noise_n, cfg->detector, cfg->snr_gate_db);
@@ -457,17 +513,17 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
         const size_t o = (size_t)f0 * h->cfg.n_bands * h->cfg.n_rx;
-        rc = run_iir(h, rx + (size_t)f0 * h->cfg.n_rx, h->d_y, n, s);
+        rc = run_iir(h, rx + (size_t)f0 * h->cfg.n_rx, h->sc.y, n, s);
         if (rc) return rc;
         if (h->long_path) {
             LongParams q = h->lbase;
-            q.fir_rx = 0; q.d_in = h->d_y; q.band_out = band_sig + o;
+            q.fir_rx = 0; q.d_in = h->sc.y; q.band_out = band_sig + o;
             rc = launch_long_fir(q, n, s);
             if (rc) return rc;
             continue;
         }
         BandParams p = h->base;
-        p.mode = MODE_Y_FIR; p.do_corr = 0; p.d_in = h->d_y; p.band_out = band_sig + o;
+        p.mode = MODE_Y_FIR; p.do_corr = 0; p.d_in = h->sc.y; p.band_out = band_sig + o;
         rc = launch_band(p, n, s);
         if (rc) return rc;
     }
@@ -527,16 +583,16 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
         if (h->long_path) {
             LongParams q = h->lbase;
             q.det_io = corr + (size_t)f0 * nb * q.L; q.det_stride = q.L; q.det_off = q.half; q.write_mutated = 1;
-            q.res_out = h->d_res;
+            q.res_out = h->sc.res;
             rc = launch_long_detect(q, n, s);
         } else {
             BandParams p = h->base;
             p.mode = MODE_CORR; p.do_corr = 1; p.write_corr_mutated = 1;
-            p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->d_res;
+            p.corr_io = corr + (size_t)f0 * nb * p.L; p.res_out = h->sc.res;
             rc = launch_band(p, n, s);
         }
         if (rc) return rc;
-        rc = launch_unpack_res(h->d_res, peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb,
+        rc = launch_unpack_res(h->sc.res, peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb,
                                amplitude ? amplitude + (size_t)f0 * nb : nullptr, n * nb, s);
         if (rc) return rc;
     }
@@ -556,11 +612,11 @@ int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope,
         if (rc) return rc;
         EnvParams q = h->ebase;
         const size_t o = (size_t)f0 * nb;
-        q.corr = corr + o * q.L; q.env_out = envelope ? envelope + o * q.L : nullptr; q.res_out = h->d_env;
+        q.corr = corr + o * q.L; q.env_out = envelope ? envelope + o * q.L : nullptr; q.res_out = h->sc.env;
         q.peaks_out = peaks ? peaks + o * kEnvMaxPeaks : nullptr;
         rc = launch_corr_env(q, n, s);
         if (rc) return rc;
-        rc = launch_unpack_env(h->d_env, peak_idx ? peak_idx + o : nullptr, snr_db ? snr_db + o : nullptr,
+        rc = launch_unpack_env(h->sc.env, peak_idx ? peak_idx + o : nullptr, snr_db ? snr_db + o : nullptr,
                                quality ? quality + o : nullptr, n_peaks ? n_peaks + o : nullptr, n * nb, s);
         if (rc) return rc;
     }
@@ -583,9 +639,9 @@ int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* s
         int rc = ensure_scratch(h, n);
         if (rc) return rc;
         rc = launch_pack_res(peak_idx + (size_t)f0 * nb, snr_db + (size_t)f0 * nb, amplitude + (size_t)f0 * nb,
-                             h->d_res, n * nb, s);
+                             h->sc.res, n * nb, s);
         if (rc) return rc;
-        rc = launch_fuse(fuse_params(h, h->d_res, out + f0, nullptr, nullptr, n), s);
+        rc = launch_fuse(fuse_params(h, h->sc.res, out + f0, nullptr, nullptr, n), s);
         if (rc) return rc;
     }
     return ECHO_OK;
@@ -600,9 +656,11 @@ int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const
     return launch_kalman(k, static_cast<hipStream_t>(stream));
 }
 
+// ext: scratch of a single pass provided by the caller of chain_impl (echo_chain_noalloc); null = the handle's own,
+// grown on demand.  With ext nothing is allocated, no prefetched IIR is consumed and no timing events are recorded.
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
-                      double* quality) {
+                      double* quality, const Scratch* ext = nullptr) {
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) return ECHO_ERR_UNSUPPORTED;
@@ -618,7 +676,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     // Calls of many passes pipeline themselves: passes of 8192 frames, the IIR of pass k+1 on the handle's stream
     // beside the band kernel of pass k.  The first IIR is exposed and the co-running band kernel is slower, so this
     // pays from about eight passes on (2.86 M against 2.76 M frames/s at a million frames).
-    const bool inner = !h->long_path && !h->capturing && h->inner_pipeline && B >= 8 * kInnerChunk &&
+    const bool inner = !ext && !h->long_path && !h->capturing && h->inner_pipeline && B >= 8 * kInnerChunk &&
                        (!kal || n_streams <= kInnerChunk);
     if (inner) chunk = kInnerChunk;
     if (kal) {
@@ -635,15 +693,16 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     }
     for (int f0 = 0; f0 < B; f0 += chunk) {
         const int n = std::min(chunk, B - f0);
-        int rc = ensure_scratch(h, n);
+        int rc = ext ? ECHO_OK : ensure_scratch(h, n);
         if (rc) return rc;
         if (full) { rc = ensure_full_scratch(h, n); if (rc) return rc; }
-        const bool prof = h->prof && f0 == 0 && h->prof_used < h->prof_slots;
+        const Scratch& sc = ext ? *ext : h->sc;
+        const bool prof = !ext && h->prof && f0 == 0 && h->prof_used < h->prof_slots;
         hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
         if (prof) (void)hipEventRecord(ev[0], s);
         // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
-        const bool pre = inner || (f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B);
-        const double* y_in = h->d_y;
+        const bool pre = inner || (!ext && f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B);
+        const double* y_in = sc.y;
         if (f0 == 0 || inner) h->pf_valid = false;         // consumed or discarded
         const int pre_slot = h->pf_slot;
         if (pre) {
@@ -655,26 +714,26 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 h->pf_valid = false;
             }
         } else {
-            rc = run_iir(h, rx + (size_t)f0 * N, h->d_y, n, s);
+            rc = run_iir(h, rx + (size_t)f0 * N, sc.y, n, s, sc.fwd);
             if (rc) return rc;
         }
         if (prof) (void)hipEventRecord(ev[1], s);
         if (h->long_path) {
             LongParams q = h->lbase;
-            q.fir_rx = 0; q.d_in = y_in; q.band_out = h->d_band;
+            q.fir_rx = 0; q.d_in = y_in; q.band_out = sc.band;
             rc = launch_long_fir(q, n, s);
             if (rc) return rc;
-            q.band_in = h->d_band; q.corr_out = h->d_pos;
+            q.band_in = sc.band; q.corr_out = sc.pos;
             const bool all_lags = q.detector != ECHO_DET_MAD;           // every other detector reports max|corr| over all lags
             q.k_begin = all_lags ? 0 : std::min(q.half + q.min_delay, q.L - 1);
             q.corr_k0 = all_lags ? 0 : q.half; q.corr_stride = all_lags ? q.L : q.L - q.half;
             rc = launch_long_corr(q, n, s);
             if (rc) return rc;
-            q.det_io = h->d_pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = h->d_res;
+            q.det_io = sc.pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = sc.res;
             rc = launch_long_detect(q, n, s);
             if (rc) return rc;
             if (spec_db) {
-                q.spec_db = 1; q.spec_in = h->d_band; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
+                q.spec_db = 1; q.spec_in = sc.band; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
                 rc = launch_long_spec(q, n, s);
                 if (rc) return rc;
             }
@@ -682,14 +741,14 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 0;
-            p.d_in = y_in; p.res_out = h->d_res; p.corr_io = h->d_corr; p.bandf_out = h->d_bandf;
+            p.d_in = y_in; p.res_out = sc.res; p.corr_io = h->d_corr; p.bandf_out = sc.bandf;
             rc = launch_band(p, n, s);
             if (rc) return rc;
         } else {
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
-            p.d_in = y_in; p.res_out = h->d_res;
-            p.bandf_out = spec_db ? h->d_bandf : nullptr;
+            p.d_in = y_in; p.res_out = sc.res;
+            p.bandf_out = spec_db ? sc.bandf : nullptr;
             rc = launch_band(p, n, s);
             if (rc) return rc;
         }
@@ -702,28 +761,28 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             // spectra of long frames are written by the long-path branch above
         } else if (full) {
             BandParams q = h->base;
-            q.spec_db = 1; q.specf_in = h->d_bandf; q.sq_out = h->d_sq;
+            q.spec_db = 1; q.specf_in = sc.bandf; q.sq_out = h->d_sq;
             q.spec_out = spec_db ? spec_db + (size_t)f0 * nb * q.nbins : h->d_spec;
             rc = launch_spec_hilbert(q, n, s);
             if (rc) return rc;
             EnvParams e = h->ebase;
-            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = h->d_env; e.peaks_out = nullptr;
+            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
             rc = launch_corr_env(e, n, s);
             if (rc) return rc;
         } else if (spec_db) {
             BandParams q = h->base;
-            q.spec_db = 1; q.specf_in = h->d_bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
+            q.spec_db = 1; q.specf_in = sc.bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
             rc = launch_spec(q, n, s);
             if (rc) return rc;
         }
         if (prof) (void)hipEventRecord(ev[3], s);
-        FuseParams fp = fuse_params(h, h->d_res, out + f0, h->d_fused, h->d_vany, n);
-        if (full) { fp.env = h->d_env; fp.sq = h->d_sq; fp.quality_out = quality ? quality + (size_t)f0 * nb * 2 : nullptr; }
+        FuseParams fp = fuse_params(h, sc.res, out + f0, sc.fused, sc.vany, n);
+        if (full) { fp.env = sc.env; fp.sq = h->d_sq; fp.quality_out = quality ? quality + (size_t)f0 * nb * 2 : nullptr; }
         rc = launch_fuse(fp, s);
         if (rc) return rc;
         if (kal) {
             KalmanParams k;
-            k.x = kalman_x; k.p = kalman_p; k.init = kalman_init; k.z = h->d_fused; k.valid = h->d_vany;
+            k.x = kalman_x; k.p = kalman_p; k.init = kalman_init; k.z = sc.fused; k.valid = sc.vany;
             k.out = nullptr; k.rec = out + f0; k.S = n_streams; k.T = n / n_streams;
             k.q = h->cfg.kalman_q; k.r = h->cfg.kalman_r;
             rc = launch_kalman(k, s);
@@ -747,6 +806,29 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality, double* kalman_x,
                     double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
     return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
+}
+
+int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
+                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
+    if (!h || B < 0) return ECHO_ERR_INVALID;
+    if (B == 0) return ECHO_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != h->device || !h->noalloc) return ECHO_ERR_INVALID;
+    if (B > h->max_chunk) return ECHO_ERR_TOO_LARGE;        // one internal pass only
+    Scratch sc;
+    if (!carve_scratch(h, B, h->noalloc, kNoallocBytes, sc)) return ECHO_ERR_TOO_LARGE;
+    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, false, nullptr, &sc);
+}
+
+int echo_noalloc_max_frames(EchoHandle* h) {
+    if (!h) return ECHO_ERR_INVALID;
+    int lo = 0, hi = h->max_chunk;                          // largest B whose scratch fits the static array
+    Scratch sc;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (carve_scratch(h, mid, h->noalloc, kNoallocBytes, sc)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long long first_frame,

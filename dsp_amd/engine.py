@@ -194,6 +194,37 @@ class EchoEngine:
                                            B, S, self._stream()), "echo_chain")
         return out, spec
 
+    def chain_noalloc(self, rx: torch.Tensor, out: torch.Tensor, spec_out: Optional[torch.Tensor] = None,
+                      n_streams: Optional[int] = None, kalman: Optional["BatchedKalman"] = None):
+        """``chain`` (named mode) through the entry point that allocates nothing: every buffer is the caller's
+        (``rx`` [B,N] f32, ``out`` uint8 [B,64], ``spec_out`` f32 [B,nb,bins] or None), the pass's scratch is the
+        library's fixed per-GPU array.  B <= ``noalloc_max_frames()``; larger batches raise EchoError."""
+        B = rx.shape[0]
+        nb, N, nbins = self.cfg.n_bands, self.cfg.n_rx, self.cfg.n_bins
+        for t, shape, dt, name in ((rx, (B, N), torch.float32, "rx"), (out, (B, 64), torch.uint8, "out"),
+                                   (spec_out, (B, nb, nbins), torch.float32, "spec_out")):
+            if t is None and name == "spec_out":
+                continue
+            if (not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != dt or tuple(t.shape) != shape
+                    or not t.is_contiguous()):
+                raise _lib.EchoError(f"chain_noalloc: {name} must be a contiguous {dt} tensor of shape {shape} on {self.device}")
+        S = n_streams if n_streams is not None else (kalman.S if kalman is not None else max(B, 1))
+        kx = kp = ki = None
+        if kalman is not None:
+            if kalman.S != S:
+                raise _lib.EchoError("chain_noalloc: kalman.S differs from n_streams")
+            kx, kp, ki = kalman.x, kalman.p, kalman.init
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.echo_chain_noalloc(self._h, _ptr(rx), _ptr(out), _ptr(spec_out), _ptr(kx), _ptr(kp),
+                                                   _ptr(ki), B, S, self._stream()), "echo_chain_noalloc")
+        return out, spec_out
+
+    def noalloc_max_frames(self) -> int:
+        n = self.lib.echo_noalloc_max_frames(self._h)
+        if n < 0:
+            _lib.check(n, "echo_noalloc_max_frames")
+        return n
+
     def synth_frames(self, count: int, first_frame: int = 0, seed: int = 1234, out=None) -> torch.Tensor:
         """``count`` synthetic rx frames generated in device memory (frame g = a function of (seed, g)); float32
         [count, n_rx] on the int16 grid.  Same recipe as dsp_amd.synth with its own random stream."""

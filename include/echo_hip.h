@@ -32,7 +32,8 @@ enum {
     ECHO_ERR_UNSUPPORTED = -2,  /* configuration does not fit this build's kernels        */
     ECHO_ERR_NOMEM = -3,        /* device allocation failed                               */
     ECHO_ERR_HIP = -4,          /* a HIP runtime call or kernel launch failed             */
-    ECHO_ERR_NODEVICE = -5      /* no gfx950 device visible                               */
+    ECHO_ERR_NODEVICE = -5,     /* no gfx950 device visible                               */
+    ECHO_ERR_TOO_LARGE = -6     /* echo_chain_noalloc: batch beyond the fixed scratch     */
 };
 
 /* detector / confidence / fusion variants (the three first_strong_peak generations the reference ships) */
@@ -174,6 +175,22 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality,
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
+
+/* echo_chain without any allocation (no counterpart in the reference).  For callers that cannot call hipMalloc: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments and results as
+ * echo_chain; the scratch of the pass (IIR forward output, IIR result, float32 band signal, detector records, fused
+ * ranges) lives in a file-scope device array of ECHO_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds
+ * until the process ends.  B is limited to what fits: echo_noalloc_max_frames(h) (256 frames for the reference's
+ * constants N = 4282, three bands, order 6); beyond it ECHO_ERR_TOO_LARGE and nothing runs.  The call never invokes
+ * hipMalloc/hipFree, does not grow the handle's scratch, ignores a pending echo_chain_prefetch and records no timing
+ * events.  It must be issued with the handle's device current.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (different streams or handles) race; calls on one stream are ordered and safe. */
+#define ECHO_NOALLOC_SCRATCH_BYTES (72u << 20)
+int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
+                       double* kalman_x, double* kalman_p, uint8_t* kalman_init,
+                       int B, int n_streams, void* stream);
+/* Largest B echo_chain_noalloc accepts for this handle's configuration (>= 0), or a negative ECHO_ERR_*. */
+int echo_noalloc_max_frames(EchoHandle* h);
 
 /* Synthetic rx frames generated in device memory (no counterpart in the reference, which records from a sound card;
  * the result has the form AudioIO.record delivers, airSonar_optimized.py:573: int16 samples / 2**15 as float32).
