@@ -75,6 +75,10 @@ struct EchoHandle {
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
+    // envelope plans for signals other than the correlation (echo_envelope_rows), made on first use
+    struct EnvPlan { int L, smooth; EnvParams p; cpx<double> *roots, *wn, *wl, *bsw, *bsb; };
+    std::vector<EnvPlan> env_plans;
+    EnvRes* d_env_rows = nullptr; size_t env_rows_cap = 0;
     Scratch sc;                            // allocated by ensure_scratch
     unsigned char* noalloc = nullptr;      // device address of this device's static scratch array (echo_chain_noalloc)
     int max_chunk = 16384;                 // frames per internal pass of echo_chain
@@ -186,6 +190,7 @@ int ensure_full_scratch(EchoHandle* h, int frames) {
 // corun: the IIR will run beside the arithmetic-bound kernels of another batch; from 8192 frames on the lane
 // mapping (half the instruction issue of the quad mapping) is then the better neighbour.
 int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, double* fwd = nullptr, bool corun = false) {
+    if (h->cfg.iir_ncoef == 1) return launch_iir_order0(rx, y, h->d_b, B, h->cfg.n_rx, h->cfg.n_bands, s);
     IirParams p;
     p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->sc.fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands;
@@ -271,6 +276,13 @@ FuseParams fuse_params(EchoHandle* h, const BandRes* res, EchoResult* out, doubl
     return p;
 }
 
+// The handle's tables, scratch and streams live on the device that was current in echo_create; a call issued with
+// another device current would allocate and launch there.
+bool on_device(const EchoHandle* h) {
+    int dev = -1;
+    return h && hipGetDevice(&dev) == hipSuccess && dev == h->device;
+}
+
 bool detector_supported(const EchoHandle* h) {
     const int d = h->cfg.detector;
     return h->long_path ? (d >= ECHO_DET_MEDIAN && d <= ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
@@ -298,10 +310,12 @@ const char* echo_strerror(int code) {
 int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (!cfg || !out) return ECHO_ERR_INVALID;
     *out = nullptr;
-    if (cfg->n_bands < 1 || cfg->n_bands > ECHO_MAX_BANDS || !cfg->b || !cfg->a || !cfg->zi || !cfg->taps ||
-        !cfg->chirps || cfg->n_rx < 64 || cfg->n_chirp < 1 || cfg->n_taps < 1 || cfg->fs <= 0)
+    if (cfg->n_bands < 1 || cfg->n_bands > ECHO_MAX_BANDS || !cfg->b || !cfg->a || (!cfg->zi && cfg->iir_ncoef > 1) ||
+        !cfg->taps || !cfg->chirps || cfg->n_rx < 64 || cfg->n_chirp < 1 || cfg->n_taps < 1 || cfg->fs <= 0)
         return ECHO_ERR_INVALID;
-    if (cfg->iir_ncoef != 13 && cfg->iir_ncoef != 17) return ECHO_ERR_UNSUPPORTED;
+    // order 6 / 8 band-passes (13 / 17 coefficients), or order zero: the identity filter ([1], [1], [1]) design_filters
+    // falls back to when a design fails (airSonar_optimized.py:178-182)
+    if (cfg->iir_ncoef != 13 && cfg->iir_ncoef != 17 && cfg->iir_ncoef != 1) return ECHO_ERR_UNSUPPORTED;
     if (3 * cfg->iir_ncoef + 1 > 64 || 3 * cfg->iir_ncoef >= cfg->n_rx) return ECHO_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ECHO_ERR_NODEVICE;
@@ -357,7 +371,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
     up(dev_upload(&h->d_b, cfg->b, (size_t)nb * nc));
     up(dev_upload(&h->d_a, cfg->a, (size_t)nb * nc));
-    up(dev_upload(&h->d_zi, cfg->zi, (size_t)nb * (nc - 1)));
+    if (nc > 1) up(dev_upload(&h->d_zi, cfg->zi, (size_t)nb * (nc - 1)));
     up(dev_upload(&h->d_taps_rev, t.taps_rev.data(), t.taps_rev.size()));
     up(dev_upload(&h->d_chirp, t.chirp.data(), t.chirp.size()));
     if (!h->long_path) {
@@ -404,7 +418,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         }
         if (rc == ECHO_OK) rc = long_kernels_prepare(h->lbase);
     }
-    if (rc == ECHO_OK && iir_kernel_prepare() != 0) rc = ECHO_ERR_HIP;
+    if (rc == ECHO_OK && nc > 1 && iir_kernel_prepare() != 0) rc = ECHO_ERR_HIP;
     std::memset(&h->ebase, 0, sizeof(h->ebase));
     if (rc == ECHO_OK && !h->long_path &&
         plan_env(h->ebase, cfg->n_rx + cfg->n_chirp - 1, nb, cfg->min_delay, 5)) {
@@ -438,6 +452,10 @@ void echo_destroy(EchoHandle* h) {
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pl : h->env_plans) {
+        (void)hipFree(pl.roots); (void)hipFree(pl.wn); (void)hipFree(pl.wl); (void)hipFree(pl.bsw); (void)hipFree(pl.bsb);
+    }
+    (void)hipFree(h->d_env_rows);
     if (h->pf_stream) {
         (void)hipStreamSynchronize(h->pf_stream);
         (void)hipStreamDestroy(h->pf_stream);
@@ -450,6 +468,7 @@ void echo_destroy(EchoHandle* h) {
 }
 
 int echo_reserve(EchoHandle* h, int max_frames) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (!h || max_frames < 1) return ECHO_ERR_INVALID;
     return ensure_scratch(h, std::min(max_frames, h->max_chunk));
 }
@@ -489,6 +508,7 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
 }
 
 int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
@@ -505,6 +525,7 @@ int echo_fir_bank(EchoHandle* h, const float* rx, double* out, int B, void* stre
 }
 
 int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !band_sig || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -531,6 +552,7 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
 }
 
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !band_sig || !spec || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
@@ -553,6 +575,7 @@ int echo_mag2db(const float* x, float* out, size_t n, void* stream) {
 }
 
 int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !band_sig || !corr || B < 0) return ECHO_ERR_INVALID;
     if (h->long_path) {
@@ -571,6 +594,7 @@ int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, v
 
 int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db, double* amplitude,
                            int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !corr || !peak_idx || !snr_db || B < 0) return ECHO_ERR_INVALID;
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
@@ -601,6 +625,7 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
 
 int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
                             double* quality, int32_t* n_peaks, int32_t* peaks, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !corr || B < 0) return ECHO_ERR_INVALID;
     if (!h->has_env) return ECHO_ERR_UNSUPPORTED;
@@ -630,6 +655,7 @@ int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream) {
 
 int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* snr_db, const double* amplitude,
                          EchoResult* out, int B, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !peak_idx || !snr_db || !amplitude || !out || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -647,13 +673,137 @@ int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* s
     return ECHO_OK;
 }
 
-int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid,
-                       double* out, int S, int T, void* stream) {
-    if (!h || !x || !p || !init || !z || !valid || S < 0 || T < 0) return ECHO_ERR_INVALID;
+int echo_kalman_update_qr(double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid, double* out,
+                          int S, int T, double q, double r, void* stream) {
+    if (!x || !p || !init || !z || !valid || S < 0 || T < 0) return ECHO_ERR_INVALID;
     KalmanParams k;
     k.x = x; k.p = p; k.init = init; k.z = z; k.valid = valid; k.out = out; k.rec = nullptr;
-    k.S = S; k.T = T; k.q = h->cfg.kalman_q; k.r = h->cfg.kalman_r;
+    k.S = S; k.T = T; k.q = q; k.r = r;
     return launch_kalman(k, static_cast<hipStream_t>(stream));
+}
+
+int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid,
+                       double* out, int S, int T, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
+    if (!h) return ECHO_ERR_INVALID;
+    return echo_kalman_update_qr(x, p, init, z, valid, out, S, T, h->cfg.kalman_q, h->cfg.kalman_r, stream);
+}
+
+int echo_band_confidence(EchoHandle* h, const double* snr_db, const double* amplitude, const int32_t* band_idx,
+                         double* conf, int n, void* stream) {
+    if (h && n == 0) return ECHO_OK;
+    if (!h || !snr_db || !amplitude || !band_idx || !conf || n < 0) return ECHO_ERR_INVALID;
+    if (!on_device(h)) return ECHO_ERR_INVALID;
+    return launch_band_confidence(snr_db, amplitude, band_idx, conf, n, h->cfg.confidence, h->cfg.freq_weights,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int echo_normalize_confidences(const double* conf, double* out, int rows, int n, void* stream) {
+    if (rows == 0) return ECHO_OK;
+    if (!conf || !out || rows < 0 || n < 1) return ECHO_ERR_INVALID;
+    return launch_normalize_conf(conf, out, rows, n, static_cast<hipStream_t>(stream));
+}
+
+int echo_xcorr(const double* a, const double* b, double* out, int rows, int n, int m, void* stream) {
+    if (rows == 0) return ECHO_OK;
+    if (!a || !b || !out || rows < 0 || n < 1 || m < 1) return ECHO_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int r0 = 0; r0 < rows; r0 += 65535) {
+        const int nr = std::min(65535, rows - r0);
+        const int rc = launch_xcorr(a + (size_t)r0 * n, b, out + (size_t)r0 * (n + m - 1), nr, n, m, s);
+        if (rc) return rc == -2 ? ECHO_ERR_UNSUPPORTED : ECHO_ERR_HIP;
+    }
+    return ECHO_OK;
+}
+
+int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int rows, void* stream) {
+    if (h && rows == 0) return ECHO_OK;
+    if (!h || !x || !spec || rows < 0) return ECHO_ERR_INVALID;
+    if (!on_device(h)) return ECHO_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the spectrum kernels take one workgroup per row and no per-band table: rows are passed as frames of one band
+    const int step = h->long_path ? 65535 : (1 << 20);
+    for (int r0 = 0; r0 < rows; r0 += step) {
+        const int nr = std::min(step, rows - r0);
+        int rc;
+        if (h->long_path) {
+            LongParams q = h->lbase;
+            q.nb = 1; q.spec_db = db ? 1 : 0;
+            q.spec_in = x + (size_t)r0 * q.N; q.spec_out = spec + (size_t)r0 * q.nbins;
+            rc = launch_long_spec(q, nr, s);
+        } else {
+            BandParams p = h->base;
+            p.nb = 1; p.spec_db = db ? 1 : 0;
+            p.specd_in = x + (size_t)r0 * p.N; p.spec_out = spec + (size_t)r0 * p.nbins;
+            rc = launch_spec(p, nr, s);
+        }
+        if (rc) return rc;
+    }
+    return ECHO_OK;
+}
+
+// plan (and device tables) of the envelope kernel for rows of `len` samples smoothed over `smooth`, made once
+static int env_plan_for(EchoHandle* h, int len, int smooth, EnvParams** out) {
+    for (auto& pl : h->env_plans)
+        if (pl.L == len && pl.smooth == smooth) { *out = &pl.p; return ECHO_OK; }
+    EchoHandle::EnvPlan e;
+    std::memset(&e, 0, sizeof(e));
+    e.L = len; e.smooth = smooth;
+    if (!plan_env(e.p, len, 1, 0, smooth)) return ECHO_ERR_UNSUPPORTED;
+    std::vector<cpx<double>> er, ewn, ewl, bw, bb;
+    env_tables(e.p, er, ewn, ewl);
+    int rc = ECHO_OK;
+    auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
+    up(dev_upload(&e.roots, er.data(), er.size()));
+    up(dev_upload(&e.wn, ewn.data(), ewn.size()));
+    up(dev_upload(&e.wl, ewl.data(), ewl.size()));
+    if (e.p.bs_m) {
+        env_bs_tables(e.p, bw, bb);
+        up(dev_upload(&e.bsw, bw.data(), bw.size()));
+        up(dev_upload(&e.bsb, bb.data(), bb.size()));
+    }
+    if (rc == ECHO_OK) rc = env_kernel_prepare(e.p);
+    if (rc != ECHO_OK) {
+        (void)hipFree(e.roots); (void)hipFree(e.wn); (void)hipFree(e.wl); (void)hipFree(e.bsw); (void)hipFree(e.bsb);
+        return rc;
+    }
+    e.p.roots = e.roots; e.p.wn = e.wn; e.p.wl = e.wl; e.p.bs_w = e.bsw; e.p.bs_bhat = e.bsb;
+    h->env_plans.push_back(e);
+    *out = &h->env_plans.back().p;
+    return ECHO_OK;
+}
+
+int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_window, int min_delay, double* envelope,
+                       int32_t* peak_idx, double* snr_db, double* quality, int32_t* n_peaks, int32_t* peaks, int rows,
+                       void* stream) {
+    if (h && rows == 0) return ECHO_OK;
+    if (!h || !x || rows < 0 || len < 1 || min_delay < 0) return ECHO_ERR_INVALID;
+    if (!on_device(h)) return ECHO_ERR_INVALID;
+    if (h->capturing) return ECHO_ERR_INVALID;
+    EnvParams* plan = nullptr;
+    int rc = env_plan_for(h, len, smooth_window, &plan);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int step = 65535;
+    const size_t need = (size_t)std::min(rows, step);
+    if (need > h->env_rows_cap) {
+        (void)hipFree(h->d_env_rows); h->d_env_rows = nullptr; h->env_rows_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_env_rows), need * sizeof(EnvRes)) != hipSuccess) return ECHO_ERR_NOMEM;
+        h->env_rows_cap = need;
+    }
+    for (int r0 = 0; r0 < rows; r0 += step) {
+        const int nr = std::min(step, rows - r0);
+        EnvParams q = *plan;
+        q.nb = 1; q.min_delay = min_delay;
+        q.corr = x + (size_t)r0 * len; q.env_out = envelope ? envelope + (size_t)r0 * len : nullptr;
+        q.res_out = h->d_env_rows; q.peaks_out = peaks ? peaks + (size_t)r0 * kEnvMaxPeaks : nullptr;
+        rc = launch_corr_env(q, nr, s);
+        if (rc) return rc;
+        rc = launch_unpack_env(h->d_env_rows, peak_idx ? peak_idx + r0 : nullptr, snr_db ? snr_db + r0 : nullptr,
+                               quality ? quality + r0 : nullptr, n_peaks ? n_peaks + r0 : nullptr, nr, s);
+        if (rc) return rc;
+    }
+    return ECHO_OK;
 }
 
 // ext: scratch of a single pass provided by the caller of chain_impl (echo_chain_noalloc); null = the handle's own,
@@ -661,6 +811,7 @@ int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
                       double* quality, const Scratch* ext = nullptr) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) return ECHO_ERR_UNSUPPORTED;
@@ -833,6 +984,7 @@ int echo_noalloc_max_frames(EchoHandle* h) {
 
 int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long long first_frame,
                       unsigned long long seed, void* stream) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (!h || !tx_mix || !rx || B < 0 || first_frame < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = h->cfg.n_rx;
@@ -846,6 +998,7 @@ int echo_synth_frames(EchoHandle* h, const float* tx_mix, float* rx, int B, long
 }
 
 int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
+    if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (!h || !rx || B < 1) return ECHO_ERR_INVALID;
     if (B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
     int rc = ensure_prefetch(h, B);
@@ -868,7 +1021,7 @@ struct EchoGraph {
 
 int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, EchoGraph** graph) {
-    if (!h || !graph || !stream || B < 1 || B > h->max_chunk) return ECHO_ERR_INVALID;
+    if (!h || !graph || !stream || B < 1 || B > h->max_chunk || !on_device(h)) return ECHO_ERR_INVALID;
     *graph = nullptr;
     int rc = ensure_scratch(h, B);          // allocate before the capture: nothing inside it may allocate
     if (rc) return rc;

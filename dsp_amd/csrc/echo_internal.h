@@ -70,5 +70,10 @@ int launch_fuse(const FuseParams& p, hipStream_t s);
 int launch_kalman(const KalmanParams& p, hipStream_t s);
 int launch_argmax(const double* x, int32_t* out, int rows, int n, hipStream_t s);
 int launch_mag2db(const float* x, float* out, size_t n, hipStream_t s);
+int launch_band_confidence(const double* snr, const double* amp, const int32_t* band, double* out, int n, int kind,
+                           const double* fw, hipStream_t s);
+int launch_normalize_conf(const double* conf, double* out, int rows, int n, hipStream_t s);
+int launch_iir_order0(const float* rx, double* y, const double* b, int B, int N, int nb, hipStream_t s);
+int launch_xcorr(const double* a, const double* b, double* out, int rows, int n, int m, hipStream_t s);   // -2: b too long for LDS
 
 }  // namespace echo

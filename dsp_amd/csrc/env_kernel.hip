@@ -19,9 +19,17 @@ __global__ __launch_bounds__(kEnvNT, 4) void corr_env_kernel(EnvParams p) {
 #undef ECHO_SYNC
 }
 
+// The limit is a property of the kernel, not of a plan: it only ever grows (per device), so that plans with a smaller
+// LDS footprint prepared later do not lower it under the larger ones.
 int env_kernel_prepare(const EnvParams& p) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(corr_env_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, p.smem_bytes) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
+    static int prepared[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ECHO_ERR_HIP;
+    if (p.smem_bytes <= prepared[dev]) return ECHO_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(corr_env_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.smem_bytes) != hipSuccess) return ECHO_ERR_HIP;
+    prepared[dev] = p.smem_bytes;
+    return ECHO_OK;
 }
 
 int launch_corr_env(const EnvParams& p, int B, hipStream_t s) {

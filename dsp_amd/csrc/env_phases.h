@@ -49,6 +49,12 @@ struct EnvParams {
     int32_t* peaks_out;                // optional [B][nb][kEnvMaxPeaks]: corr_peaks in ascending order, -1 padded
     int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
     int aux_cmax, aux_cmin, aux_cpos, cand_cap;  // byte offsets inside the auxiliary buffer
+    // Lengths whose half n has a prime factor beyond the mixed-radix passes (e.g. the 4282-sample band signal,
+    // n = 2141 prime) take the half-length transforms as Bluestein convolutions of cyclic length bs_m >= 2n - 1 (a
+    // length the mixed-radix FFT handles with small radices): `plan` is then the plan of bs_m, not of n.
+    int bs_m;                          // 0: direct transform of length n
+    const cpx<double>* bs_w;           // global, n: exp(-i*pi*k^2/n)
+    const cpx<double>* bs_bhat;        // global, bs_m: FFT_m of the wrapped conj(w) sequence, divided by bs_m
     int stop_after;                    // development aid: leave the sequence after stage 1..5 (0 = run everything)
 };
 
@@ -60,17 +66,19 @@ struct EnvMisc {
     int undecided, best_idx, n_final, n_cand;
 };
 
+constexpr int kEnvBsMaxRadix = 16;     // Bluestein: largest radix of the cyclic length's passes
+
 inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     p.L = L; p.n = L / 2; p.nb = nb; p.min_delay = min_delay; p.smooth = smooth; p.distance = L / 50;
+    p.bs_m = 0; p.bs_w = nullptr; p.bs_bhat = nullptr;
     if (L % 2 != 0 || L < 8 || smooth < 1 || smooth % 2 == 0 || smooth > 9) return false;
     if (p.distance < 1) p.distance = 1;
-    if (!gfft_plan(p.plan, p.n)) return false;
-    int off = 0;
-    p.off_buf0 = off; off += p.n * 16;
-    p.off_buf1 = off; off += p.n * 16;
-    p.off_roots = off; off += p.plan.nroots * 16;
-    p.off_misc = off; off += ((int)sizeof(EnvMisc) + 15) & ~15;
-    p.smem_bytes = off;
+    if (!gfft_plan(p.plan, p.n)) {
+        bool found = false;
+        for (int m = 2 * p.n - 1; m <= 2 * p.n + 512 && !found; ++m)
+            if (gfft_plan(p.plan, m) && p.plan.radix[0] <= kEnvBsMaxRadix) { p.bs_m = m; found = true; }
+        if (!found) return false;
+    }
     // After the smoothing the buffer that held the raw envelope is reused: first as reduction scratch (7 quantities
     // x nt partials + fold area), then for the candidate states, the per-chunk extrema and the list of kept peaks.
     const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
@@ -79,8 +87,47 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     p.aux_cmin = aux; aux += 5 * nchunk * 8;
     p.cand_cap = L / 2 + 2;                          // strict local maxima are at least two samples apart
     p.aux_cpos = aux; aux += p.cand_cap * 7;         // int pos[cap]; byte state[cap], fk[cap], fu[cap]
+    // each of the two buffers holds the transform (n, or bs_m complex doubles) and, for short signals, at least the
+    // reduction scratch and the auxiliary arrays
+    int bufbytes = (p.bs_m ? p.bs_m : p.n) * 16;
+    if (bufbytes < (7 * kEnvNT + 7 * 64) * 8) bufbytes = (7 * kEnvNT + 7 * 64) * 8;
+    if (bufbytes < aux) bufbytes = aux;
+    bufbytes = (bufbytes + 15) & ~15;
+    int off = 0;
+    p.off_buf0 = off; off += bufbytes;
+    p.off_buf1 = off; off += bufbytes;
+    p.off_roots = off; off += p.plan.nroots * 16;
+    p.off_misc = off; off += ((int)sizeof(EnvMisc) + 15) & ~15;
+    p.smem_bytes = off;
     if (p.n > kEnvIterN * kEnvNT) return false;
-    return off <= 160 * 1024 && p.n * 16 >= (7 * kEnvNT + 7 * 64) * 8 && p.n * 16 >= aux;
+    return off <= 160 * 1024;
+}
+
+// Bluestein tables: w[k] = exp(-i*pi*k^2/n) with k^2 reduced mod 2n in integers; bhat = DFT_m of
+// c[j] = conj(w[|j|]) for |j| < n wrapped to length m, divided by m (direct O(m * n) sums in long double: once per plan).
+inline void env_bs_tables(const EnvParams& p, std::vector<cpx<double>>& w, std::vector<cpx<double>>& bhat) {
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const int n = p.n, m = p.bs_m;
+    w.resize(n); bhat.resize(m);
+    std::vector<long double> cr(n), ci(n);
+    for (int k = 0; k < n; ++k) {
+        const long long k2 = ((long long)k * k) % (2LL * n);
+        const long double a = pi * (long double)k2 / (long double)n;
+        cr[k] = cosl(a); ci[k] = sinl(a);              // conj(w[k]) = exp(+i a)
+        w[k] = cpx<double>{(double)cr[k], (double)(-ci[k])};
+    }
+    // exp(-2*pi*i*t/m) table, indices reduced mod m in integers
+    std::vector<long double> er(m), ei(m);
+    for (int t = 0; t < m; ++t) { const long double a = -2.0L * pi * (long double)t / (long double)m; er[t] = cosl(a); ei[t] = sinl(a); }
+    for (int q = 0; q < m; ++q) {
+        // sum_j c[j] e(-q j) + sum_{j>=1} c[j] e(+q j)  =  c[0] + sum_{j>=1} c[j] * 2 cos(2 pi q j / m)
+        long double sr = cr[0], si = ci[0];
+        for (int j = 1; j < n; ++j) {
+            const long double c2 = 2.0L * er[(int)(((long long)q * j) % m)];
+            sr += cr[j] * c2; si += ci[j] * c2;
+        }
+        bhat[q] = cpx<double>{(double)(sr / (long double)m), (double)(si / (long double)m)};
+    }
 }
 
 inline void env_tables(const EnvParams& p, std::vector<cpx<double>>& roots, std::vector<cpx<double>>& wn,
@@ -133,6 +180,34 @@ ECHO_HD EnvPart1 ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsig
 ECHO_HD void ph_env_fft_pass(int tid, int nt, const EnvParams& p, unsigned char* smem, int ps, int src, bool inv) {
     const cpx<double>* r = reinterpret_cast<const cpx<double>*>(smem + p.off_roots) + p.plan.root_off[ps];
     gfft_pass<double>(tid, nt, p.plan, ps, env_buf(smem, p, src), env_buf(smem, p, src ^ 1), r, p.wn, inv);
+}
+
+// Bluestein steps around the passes of length bs_m (in place on buffer `which`).
+// pre:  a[i] = z[i] * w[i] (z conjugated first for the inverse transform), zero beyond n
+ECHO_HD void ph_env_bs_pre(int tid, int nt, const EnvParams& p, unsigned char* smem, int which, bool conj_in) {
+    cpx<double>* z = env_buf(smem, p, which);
+    for (int i = tid; i < p.bs_m; i += nt) {
+        if (i >= p.n) { z[i] = cpx<double>{0.0, 0.0}; continue; }
+        const cpx<double> w = p.bs_w[i];
+        const double zx = z[i].x, zy = conj_in ? -z[i].y : z[i].y;
+        z[i] = cpx<double>{zx * w.x - zy * w.y, zx * w.y + zy * w.x};
+    }
+}
+ECHO_HD void ph_env_bs_mul(int tid, int nt, const EnvParams& p, unsigned char* smem, int which) {
+    cpx<double>* z = env_buf(smem, p, which);
+    for (int i = tid; i < p.bs_m; i += nt) {
+        const cpx<double> b = p.bs_bhat[i], v = z[i];
+        z[i] = cpx<double>{v.x * b.x - v.y * b.y, v.x * b.y + v.y * b.x};
+    }
+}
+// post: X[k] = conv[k] * w[k] (conjugated for the inverse transform), k < n
+ECHO_HD void ph_env_bs_post(int tid, int nt, const EnvParams& p, unsigned char* smem, int which, bool conj_out) {
+    cpx<double>* z = env_buf(smem, p, which);
+    for (int k = tid; k < p.n; k += nt) {
+        const cpx<double> w = p.bs_w[k], v = z[k];
+        const double re = v.x * w.x - v.y * w.y, im = v.x * w.y + v.y * w.x;
+        z[k] = cpx<double>{re, conj_out ? -im : im};
+    }
 }
 
 // Z = FFT_n(x[2m] + i x[2m+1]) -> V, the packed spectrum whose inverse half-length transform is
@@ -465,7 +540,9 @@ ECHO_HD void ph_env_peaks_out(int tid, int nt, int blk, const EnvParams& p, unsi
     const EnvCand c = env_cand(smem, p, sm_buf);
     const int nc = env_misc(smem, p)->n_cand;
     int32_t* dst = p.peaks_out + (size_t)blk * kEnvMaxPeaks;
-    for (int t = tid; t < kEnvMaxPeaks; t += nt) dst[t] = -1;
+    // every slot has exactly one writer: ranks below n_final belong to the kept peaks, the rest is padding
+    const int n_final = env_misc(smem, p)->n_final;
+    for (int t = tid; t < kEnvMaxPeaks; t += nt) if (t >= n_final) dst[t] = -1;
     for (int t = tid; t < nc; t += nt) {
         if (c.state[t] != 2) continue;
         int rank = 0;
@@ -500,24 +577,39 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
 // Barrier-separated sequence of one workgroup.  PHASE runs a statement for every thread (tid in scope); SYNC is a
 // workgroup barrier.  PART1 declares per-thread storage for the smoothing partials: a local on the device, an array
 // indexed by tid on the host.
+// One half-length transform (forward, or unnormalised inverse) of buffer cur_: the plan's passes directly, or as a
+// Bluestein convolution (pre-multiply, forward passes of length bs_m, product with bhat, inverse passes, post-multiply;
+// the inverse transform of V is conj(DFT(conj V))).
+#define ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, INV)                                                    \
+    if ((p).bs_m == 0) {                                                                                     \
+        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
+            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, INV)) SYNC                                    \
+            cur_ ^= 1;                                                                                       \
+        }                                                                                                    \
+    } else {                                                                                                 \
+        PHASE(ph_env_bs_pre(tid, nt, p, smem, cur_, INV)) SYNC                                               \
+        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
+            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, false)) SYNC                                  \
+            cur_ ^= 1;                                                                                       \
+        }                                                                                                    \
+        PHASE(ph_env_bs_mul(tid, nt, p, smem, cur_)) SYNC                                                    \
+        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
+            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, true)) SYNC                                   \
+            cur_ ^= 1;                                                                                       \
+        }                                                                                                    \
+        PHASE(ph_env_bs_post(tid, nt, p, smem, cur_, INV)) SYNC                                              \
+    }
+
 #define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
     do {                                                                                                     \
         PART1_DECL;                                                                                          \
         PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
         int cur_ = 0;                                                                                        \
         if ((p).stop_after == 6) break;                                                                      \
-        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
-            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, false)) SYNC                                  \
-            cur_ ^= 1;                                                                                       \
-            if ((p).stop_after == 7 + ps_) break;                                                            \
-        }                                                                                                    \
-        if ((p).stop_after >= 7 && (p).stop_after <= 9) break;                                                                                                    \
+        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, false)                                                  \
         if ((p).stop_after == 1) break;                                                                      \
         PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
-        for (int ps_ = 0; ps_ < (p).plan.npass; ++ps_) {                                                     \
-            PHASE(ph_env_fft_pass(tid, nt, p, smem, ps_, cur_, true)) SYNC                                   \
-            cur_ ^= 1;                                                                                       \
-        }                                                                                                    \
+        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, true)                                                   \
         if ((p).stop_after == 2) break;                                                                      \
         PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
         cur_ ^= 1;                               /* cur_: envelope */                                        \

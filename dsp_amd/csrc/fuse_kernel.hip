@@ -179,7 +179,102 @@ __global__ void mag2db_kernel(const float* x, float* out, size_t n) {
     for (; i < n; i += stride) out[i] = 20.0f * log10f(fmaxf(fabsf(x[i]), 1e-12f));
 }
 
+// calculate_band_confidence (airSonar_optimized.py:222-243; realtime_sonar.py:393 for the unclamped variant),
+// elementwise with an explicit band index per element
+__global__ void band_confidence_kernel(const double* snr, const double* amp, const int32_t* band, double* out, int n,
+                                       int kind, double fw0, double fw1, double fw2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = band[i];
+    const double fw = j == 0 ? fw0 : (j == 1 ? fw1 : fw2);
+    double c;
+    if (kind == ECHO_CONF_CLAMPED) c = fmin(fmin(snr[i] / 10.0, 1.0) * 0.5 + fmin(amp[i] / 0.1, 1.0) * 0.3 + fw * 0.2, 1.0);
+    else if (kind == ECHO_CONF_RAW) c = fmin((snr[i] / 10.0) * 0.5 + (amp[i] / 0.1) * 0.3 + fw * 0.2, 1.0);
+    else c = 0.0;
+    out[i] = c;
+}
+
+// normalize_confidences (airSonar_optimized.py:245-262): each row of n values scaled to sum to 100 (np.sum adds a
+// short row left to right), or 100 / n each when the sum is not positive; one lane per row
+__global__ void normalize_conf_kernel(const double* conf, double* out, int rows, int n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const double* c = conf + (size_t)r * n;
+    double total = 0.0;
+    for (int k = 0; k < n; ++k) total += c[k];
+    for (int k = 0; k < n; ++k) out[(size_t)r * n + k] = total > 0.0 ? (c[k] / total) * 100.0 : 100.0 / (double)n;
+}
+
+// filtfilt with the identity filter b = [b0], a = [1] that design_filters falls back to (airSonar_optimized.py:178-182):
+// lfilter of order zero forward and backward, y = (x * b0) * b0
+__global__ void iir_order0_kernel(const float* rx, double* y, const double* b, int B, int N, int nb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * nb * N;
+    if (i >= total) return;
+    const int n = (int)(i % N); const size_t fb = i / N;
+    const int band = (int)(fb % nb); const size_t f = fb / nb;
+    const double b0 = b[band];
+    y[i] = ((double)rx[f * N + n] * b0) * b0;
+}
+
+// gpu_correlate for arbitrary operands (airSonar_optimized.py:290-303): out[row][k] = sum_j apad[k + j] * b[j],
+// apad = a[row] with m - 1 zeros on either side, k < n + m - 1.  256 lanes x kR consecutive lags per workgroup, the
+// window of a and the whole of b staged in LDS, the same sliding dot (and summation order) as the band kernel.
+constexpr int kXcNT = 256;
+__global__ __launch_bounds__(kXcNT) void xcorr_kernel(const double* a, const double* b, double* out, int n, int m,
+                                                      int mgroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = n + m - 1, T = kXcNT * kR;
+    const int wlen = T + mgroups * kR, clen = (mgroups + 1) * kR;
+    double* win = reinterpret_cast<double*>(smem);
+    double* cb = win + wlen;
+    const int k0 = blockIdx.x * T;
+    const double* arow = a + (size_t)blockIdx.y * n;
+    for (int i = threadIdx.x; i < wlen; i += kXcNT) {
+        const int src = k0 + i - (m - 1);
+        win[i] = (src >= 0 && src < n) ? arow[src] : 0.0;
+    }
+    for (int i = threadIdx.x; i < clen; i += kXcNT) cb[i] = i < m ? b[i] : 0.0;
+    __syncthreads();
+    const int kk = k0 + threadIdx.x * kR;
+    if (kk >= L) return;
+    double acc[kR];
+    sliding_dot(win + threadIdx.x * kR, cb, mgroups, acc);
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+        if (kk + r < L) out[(size_t)blockIdx.y * L + kk + r] = acc[r];
+}
+
 static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -4; }
+
+int launch_band_confidence(const double* snr, const double* amp, const int32_t* band, double* out, int n, int kind,
+                           const double* fw, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(band_confidence_kernel, dim3((n + 255) / 256), dim3(256), 0, s, snr, amp, band, out, n, kind,
+                       fw[0], fw[1], fw[2]);
+    return ok();
+}
+int launch_normalize_conf(const double* conf, double* out, int rows, int n, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(normalize_conf_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, conf, out, rows, n);
+    return ok();
+}
+int launch_iir_order0(const float* rx, double* y, const double* b, int B, int N, int nb, hipStream_t s) {
+    const size_t total = (size_t)B * nb * N;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(iir_order0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rx, y, b, B, N, nb);
+    return ok();
+}
+int launch_xcorr(const double* a, const double* b, double* out, int rows, int n, int m, hipStream_t s) {
+    if (rows <= 0) return 0;
+    const int mgroups = (m + kR - 1) / kR, T = kXcNT * kR, L = n + m - 1;
+    const size_t smem = (size_t)(T + mgroups * kR + (mgroups + 1) * kR) * sizeof(double);
+    if (smem > 160 * 1024 || rows > 65535) return -2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xcorr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return -4;
+    hipLaunchKernelGGL(xcorr_kernel, dim3((L + T - 1) / T, rows), dim3(kXcNT), smem, s, a, b, out, n, m, mgroups);
+    return ok();
+}
 
 int launch_fuse(const FuseParams& p, hipStream_t s) {
     if (p.B <= 0) return 0;

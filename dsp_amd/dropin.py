@@ -1,116 +1,186 @@
-"""Drop-in spellings of the reference's module-level DSP functions, batched.
+"""Drop-in spellings of the reference's module-level DSP functions.
 
-Same names, argument meaning and "never raise for a data condition" behaviour as
-airSonar_optimized.py:185-368, with one difference that is the point of this package: the leading
-dimension may be a batch of frames.  NumPy in -> NumPy out (upload/compute/download, like the reference's
-CuPy wrappers); torch CUDA tensors in -> torch CUDA tensors out (no host round trip).
+Same names, argument order and call shapes as airSonar_optimized.py:157-368, :431-490: what
+``SonarWorker._process_band_gpu`` (:629-676) and ``process_band_with_output`` (:703-715) pass -- one band's 1-D
+signal, a chirp, a ``(b, a, taps)`` tuple, scalars -- works unchanged, and every function also takes leading batch
+dimensions.  NumPy in -> NumPy out (upload / compute / download, like the reference's CuPy wrappers); torch CUDA
+tensors in -> torch CUDA tensors out.  All arithmetic runs in the HIP library; a mis-shaped argument raises
+``EchoError`` instead of reaching a kernel.
 
 A process-wide default engine is created lazily on the current GPU; ``use_engine`` swaps it.
 """
 from __future__ import annotations
 
+from dataclasses import replace
 from typing import Optional
 
 import numpy as np
 import torch
+from scipy.signal import lfilter_zi
 
+from ._lib import EchoError
 from .config import SonarConfig, optimized_config
-from .design import calculate_sound_speed, design_filters as _design_filters, generate_chirps as _generate_chirps  # noqa: F401
+from .design import SonarTables, calculate_sound_speed, design_filters as _design_filters, generate_chirps as _generate_chirps  # noqa: F401
 from .engine import BatchedKalman, EchoEngine, records_to_numpy
 
 _engine: Optional[EchoEngine] = None
+_filter_engines = {}          # engines for (b, a, taps) tuples that are not one of the default engine's bands
 
 
 def get_engine(cfg: Optional[SonarConfig] = None) -> EchoEngine:
     global _engine
     if _engine is None or (cfg is not None and cfg != _engine.cfg):
-        _engine = EchoEngine(cfg or optimized_config())
+        use_engine(EchoEngine(cfg or optimized_config()))
     return _engine
 
 
 def use_engine(engine: EchoEngine):
     global _engine
+    if engine is not _engine:
+        for e in _filter_engines.values():
+            e.close()
+        _filter_engines.clear()
     _engine = engine
 
 
 def _is_np(x):
-    return isinstance(x, np.ndarray)
+    return not isinstance(x, torch.Tensor)
 
 
-def _back(t, like_np, squeeze):
-    if squeeze:
-        t = t[0]
+def _ret(t, like_np):
     return t.cpu().numpy() if like_np else t
 
 
+def _rows(x, e: EchoEngine, dtype, what):
+    """Any-rank input -> ([rows, n] device tensor, leading shape)."""
+    t = e._dev(x, dtype)
+    if t.dim() < 1 or t.shape[-1] < 1:
+        raise EchoError(f"{what}: expected a signal along the last axis, got shape {list(t.shape)}")
+    lead = tuple(t.shape[:-1])
+    return t.reshape(-1, t.shape[-1]), lead
+
+
+# --------------------------------------------------------------------------- set-up
 def design_filters(fs=None):
-    """airSonar_optimized.py:167-183: list of (b, a, taps), one per band."""
-    return get_engine().tables.filters
+    """airSonar_optimized.py:167-183: list of (b, a, taps), one per band, for sample rate ``fs`` (default: the
+    engine's)."""
+    e = get_engine()
+    if fs is None or fs == e.cfg.FS:
+        return e.tables.filters
+    return _design_filters(e.cfg, fs=fs)
 
 
 def generate_chirps(fs=None, duration=None):
     """airSonar_optimized.py:157-165: (tx_pcm int16, [chirp float32])."""
-    t = get_engine().tables
-    return t.tx_pcm, t.chirps_f32
+    e = get_engine()
+    if (fs is None or fs == e.cfg.FS) and (duration is None or duration == e.cfg.CHIRP_LEN):
+        return e.tables.tx_pcm, e.tables.chirps_f32
+    return _generate_chirps(e.cfg, fs=fs, duration=duration)
 
 
-def _band_of(filt, e: EchoEngine) -> int:
+# --------------------------------------------------------------------------- filtering
+def _band_of(filt, e: EchoEngine):
+    if len(filt) != 3:
+        raise EchoError("filt must be a (b, a, taps) tuple")
     for j, f in enumerate(e.tables.filters):
-        if filt is f or (len(filt) == 3 and np.array_equal(filt[2], f[2]) and np.array_equal(filt[1], f[1])):
+        if filt is f or all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(filt, f)):
             return j
-    raise ValueError("filt is not one of this engine's design_filters() entries")
+    return None
+
+
+def _engine_for_filter(filt, e: EchoEngine) -> EchoEngine:
+    """A one-band engine around a caller-supplied (b, a, taps): the same kernels with these coefficients.  The library
+    takes zero-phase IIRs of order 6 and 8 (13 / 17 coefficients) and the identity filter ([1], [1], [1]) that
+    design_filters falls back to (airSonar_optimized.py:178-182); anything else raises EchoError."""
+    b, a, taps = (np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in filt)
+    key = (b.tobytes(), a.tobytes(), taps.tobytes())
+    if key in _filter_engines:
+        return _filter_engines[key]
+    na = max(len(a), len(b))
+    bb = np.zeros(na); aa = np.zeros(na)
+    bb[:len(b)] = b; aa[:len(a)] = a
+    if aa[0] == 0:
+        raise EchoError("filt: a[0] must not be zero")
+    if aa[0] != 1.0:                                   # scipy.signal.lfilter normalises by a[0]
+        bb = bb / aa[0]; aa = aa / aa[0]
+    zi = lfilter_zi(bb, aa) if na > 1 else np.zeros(0)
+    cfg1 = replace(e.cfg, BANDS=(e.cfg.BANDS[0],), IIR_ORDER=(na - 1) // 2, FIR_TAPS=len(taps))
+    t0 = e.tables
+    tables = SonarTables(cfg=cfg1, b=bb[None], a=aa[None], zi=zi[None], taps=taps[None], chirps=t0.chirps[:1],
+                         tx_pcm=t0.tx_pcm, filters=[(b, a, taps)], chirps_f32=t0.chirps_f32[:1])
+    if len(_filter_engines) >= 8:                      # bounded cache
+        _filter_engines.pop(next(iter(_filter_engines))).close()
+    eng = EchoEngine(cfg1, e.device, tables=tables)
+    _filter_engines[key] = eng
+    return eng
 
 
 def bandpass_bank(rx):
     """All bands at once: rx [B,N] (or [N]) -> band_sig [B,nb,N] (or [nb,N])."""
     e = get_engine()
-    sq = rx.ndim == 1
-    out = e.bandpass_bank(rx[None] if sq else rx)
-    return _back(out, _is_np(rx), sq)
+    rows, lead = _rows(rx, e, torch.float32, "bandpass_bank")
+    out = e.bandpass_bank(rows)
+    return _ret(out.reshape(lead + tuple(out.shape[1:])), _is_np(rx))
 
 
 def bandpass(sig, filt):
-    """airSonar_optimized.py:185-197 for one band of design_filters(); sig [N] or [B,N]."""
+    """airSonar_optimized.py:185-197: filtfilt(b, a, sig) then fftconvolve(y, taps, 'same').  ``sig`` [N] (the
+    reference's call) or [..., N]; ``filt`` one of design_filters()'s entries or any (b, a, taps) the library holds."""
     e = get_engine()
+    rows, lead = _rows(sig, e, torch.float32, "bandpass")
     j = _band_of(filt, e)
-    sq = sig.ndim == 1
-    out = e.bandpass_bank(sig[None] if sq else sig)[:, j]
-    return _back(out, _is_np(sig), sq)
+    if j is None:
+        out = _engine_for_filter(filt, e).bandpass_bank(rows)[:, 0]
+    else:
+        out = e.bandpass_bank(rows)[:, j]
+    return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(sig))
 
 
 gpu_bandpass = bandpass
 
 
+# --------------------------------------------------------------------------- correlation / spectrum
 def gpu_correlate(a, b=None):
-    """airSonar_optimized.py:290-303.  a = band_sig [..., nb, N]; each band is correlated with its own chirp
-    (the reference passes the band's chirp as b; b is accepted and ignored when a carries all bands)."""
+    """airSonar_optimized.py:290-303: scipy.signal.correlate(a, b, 'full').  ``a`` [n] with ``b`` [m] (the reference's
+    per-band call, :639, :712) or ``a`` [..., n] with one ``b`` for every row.  With ``b`` omitted ``a`` is a whole
+    bank [..., nb, N] and every band is correlated with its own chirp."""
     e = get_engine()
-    sq = a.ndim == 2
-    out = e.correlate(a[None] if sq else a)
-    return _back(out, _is_np(a), sq)
+    if b is None:
+        t = e._dev(a, torch.float64)
+        if t.dim() < 2:
+            raise EchoError("gpu_correlate(a): without b, a must be a bank [..., n_bands, n_rx]")
+        lead = tuple(t.shape[:-2])
+        out = e.correlate(t.reshape((-1,) + tuple(t.shape[-2:])))
+        return _ret(out.reshape(lead + tuple(out.shape[1:])), _is_np(a))
+    rows, lead = _rows(a, e, torch.float64, "gpu_correlate")
+    bt = e._dev(b, torch.float64)
+    if bt.dim() != 1:
+        raise EchoError(f"gpu_correlate: b must be one-dimensional, got shape {list(bt.shape)}")
+    out = e.xcorr(rows, bt)
+    return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(a))
 
 
 def gpu_spectrum(signal):
-    """airSonar_optimized.py:332-343: |rfft| of band_sig [..., nb, N]."""
+    """airSonar_optimized.py:332-343: |rfft(signal)|, signal [N] or [..., N] (N = the engine's frame length)."""
     e = get_engine()
-    sq = signal.ndim == 2
-    out = e.spectrum(signal[None] if sq else signal, db=False)
-    return _back(out, _is_np(signal), sq)
+    rows, lead = _rows(signal, e, torch.float64, "gpu_spectrum")
+    out = e.spectrum_rows(rows, db=False)
+    return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(signal))
 
 
 def spectrum_db(band_sig):
     """mag2db(np.fft.rfft(band_sig)), airSonar_optimized.py:710."""
     e = get_engine()
-    sq = band_sig.ndim == 2
-    out = e.spectrum(band_sig[None] if sq else band_sig, db=True)
-    return _back(out, _is_np(band_sig), sq)
+    rows, lead = _rows(band_sig, e, torch.float64, "spectrum_db")
+    out = e.spectrum_rows(rows, db=True)
+    return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(band_sig))
 
 
 def mag2db(x):
     """airSonar_optimized.py:286-287 (float32 on the device)."""
     e = get_engine()
     if _is_np(x):
-        return e.mag2db(np.abs(x).astype(np.float32)).cpu().numpy()
+        return e.mag2db(np.abs(np.asarray(x)).astype(np.float32)).cpu().numpy()
     return e.mag2db(x.abs() if x.is_complex() else x)
 
 
@@ -123,112 +193,117 @@ def gpu_argmax(signal):
     out = e.argmax(signal)
     if _is_np(signal):
         out = out.cpu().numpy()
-        return int(out[0]) if signal.ndim == 1 else out
+        return int(out[0]) if np.ndim(signal) == 1 else out
     return out
 
 
+# --------------------------------------------------------------------------- detectors
 def first_strong_peak(corr, fs=None, min_delay_samples=None):
-    """airSonar_optimized.py:200-219.  corr [L] for band 0, or [nb,L], or [B,nb,L].
-    Scalar call returns (peak_idx | None, snr_db); batched calls return (int32 array with -1 for None, snr array).
-    The blind zone of ``corr`` is zeroed in place, as in the reference."""
+    """airSonar_optimized.py:200-219.  corr [L] (one band, the reference's call), or [nb,L], or [B,nb,L], with
+    L = the engine's correlation length.  The scalar call returns (peak_idx | None, snr_db); batched calls return
+    (int32 array with -1 for None, snr array).  The blind zone of ``corr`` is zeroed in place, as in the reference."""
     e = get_engine()
     cfg = e.cfg
     if min_delay_samples is not None and int(min_delay_samples) != cfg.min_delay:
-        raise ValueError("min_delay_samples differs from the engine's configuration")
+        raise EchoError("min_delay_samples differs from the engine's configuration")
+    if fs is not None and fs != cfg.FS:
+        raise EchoError("fs differs from the engine's configuration")
     is_np = _is_np(corr)
-    shape = corr.shape
-    if corr.ndim == 1:
-        full = np.zeros((1, cfg.n_bands, shape[0])) if is_np else torch.zeros((1, cfg.n_bands, shape[0]),
-                                                                               dtype=torch.float64, device=e.device)
-        full[0, 0] = corr
-    elif corr.ndim == 2:
-        full = corr[None]
+    if is_np and not isinstance(corr, np.ndarray):
+        raise EchoError("first_strong_peak writes into corr: pass a NumPy array or a torch tensor")
+    nd = corr.ndim
+    shape = tuple(corr.shape)
+    if nd not in (1, 2, 3) or shape[-1] != cfg.n_corr or (nd >= 2 and shape[-2] != cfg.n_bands):
+        raise EchoError(f"corr must be [{cfg.n_corr}], [{cfg.n_bands}, {cfg.n_corr}] or [B, {cfg.n_bands}, {cfg.n_corr}], "
+                        f"got {list(shape)}")
+    if nd == 1:
+        full = torch.zeros((1, cfg.n_bands, cfg.n_corr), dtype=torch.float64, device=e.device)
+        full[0, 0] = e._dev(corr, torch.float64)
+        dev = full
     else:
-        full = corr
-    dev = e._dev(full, torch.float64)
+        dev = e._dev(corr, torch.float64).reshape((-1, cfg.n_bands, cfg.n_corr))
+        if not is_np and dev.data_ptr() == corr.data_ptr():
+            pass                                        # mutated in place on the device
     peak, snr, _ = e.first_strong_peak(dev)
+    mutated = dev[0, 0] if nd == 1 else dev.reshape(shape)
     if is_np:
-        mut = dev.cpu().numpy()
-        if corr.ndim == 1:
-            corr[...] = mut[0, 0]
-        else:
-            corr[...] = mut.reshape(shape)
+        corr[...] = mutated.cpu().numpy()
         peak = peak.cpu().numpy(); snr = snr.cpu().numpy()
-    elif dev.data_ptr() != corr.data_ptr():
-        corr.copy_(dev[0, 0] if corr.ndim == 1 else dev.reshape(shape))
-    if corr.ndim == 1:
+    elif mutated.data_ptr() != corr.data_ptr():
+        corr.copy_(mutated)
+    if nd == 1:
         p = int(peak[0, 0]); s = float(snr[0, 0])
         return (None, 0.0) if p < 0 else (p, s)
-    if corr.ndim == 2:
+    if nd == 2:
         return peak[0], snr[0]
     return peak, snr
 
 
 def gpu_envelope_detection(signal, method="hilbert", smooth_window=5):
-    """airSonar_optimized.py:431-475 for correlation-length signals (the call at :642): Hilbert envelope,
-    ``uniform_filter1d(smooth_window)``, ``find_peaks(height = mean + 2 std, distance = len // 50, prominence = std)``
-    and ``calculate_signal_quality``.  ``signal``: [L] for one band (band 0's slot is used; the stage does not depend
-    on the band), or [nb, L], or [B, nb, L].  Returns ``(envelope, peaks, quality)`` like the reference for a 1-D
-    input; for batched input ``peaks`` is a list (per row) of index arrays.  Only method='hilbert' with
-    smooth_window=5 runs on the GPU (the band-signal call with window 3 only feeds signal_quality and lives inside
-    ``process_frames(..., mode="full")``)."""
-    if method != "hilbert" or smooth_window != 5:
-        raise ValueError("gpu_envelope_detection: the GPU path implements method='hilbert', smooth_window=5")
+    """airSonar_optimized.py:431-475: Hilbert envelope, ``uniform_filter1d(smooth_window)``,
+    ``find_peaks(height = mean + 2 std, distance = len // 50, prominence = std)`` and ``calculate_signal_quality``.
+    ``signal``: [len] -- the band signal with smooth_window 3 (:636, :708) or the correlation with 5 (:642) -- or
+    [..., len].  Returns ``(envelope, peaks, quality)`` like the reference for a 1-D input; for batched input
+    ``envelope`` and ``quality`` carry the leading axes and ``peaks`` is a flat list (row-major) of index arrays.
+    Only method='hilbert' (the one the reference's live path uses) is implemented."""
+    if method != "hilbert":
+        raise EchoError("gpu_envelope_detection: only method='hilbert' is implemented")
     e = get_engine()
     like_np = _is_np(signal)
-    x = torch.as_tensor(signal, dtype=torch.float64)
-    nd = x.dim()
-    nb, L = e.cfg.n_bands, e.cfg.n_corr
-    if nd == 1:
-        x3 = x.reshape(1, 1, L).expand(1, nb, L)
-    elif nd == 2:
-        x3 = x.reshape(1, nb, L)
-    else:
-        x3 = x
-    r = e.envelope_detection(x3.contiguous())
+    rows, lead = _rows(signal, e, torch.float64, "gpu_envelope_detection")
+    r = e.envelope_rows(rows, smooth_window=int(smooth_window), min_delay=0)
     env, q, pk = r["envelope"], r["quality"], r["peaks"].cpu().numpy()
-    peaks = [[row[row >= 0].astype(np.int64) for row in frame] for frame in pk]
-    if like_np:
-        env, q = env.cpu().numpy(), q.cpu().numpy()
-    if nd == 1:
-        return env[0, 0], peaks[0][0], float(q[0, 0])
-    if nd == 2:
-        return env[0], peaks[0], q[0]
-    return env, peaks, q
+    peaks = [row[row >= 0].astype(np.int64) for row in pk]
+    env = _ret(env.reshape(lead + (env.shape[-1],)), like_np)
+    if not lead:
+        return env, peaks[0], float(q[0])
+    return env, peaks, _ret(q.reshape(lead), like_np)
 
 
+# --------------------------------------------------------------------------- confidence / fusion / Kalman
 def calculate_band_confidence(snr, amplitude, band_idx):
-    """airSonar_optimized.py:222-243, elementwise on arrays (host arithmetic: three multiplies per element;
-    the device path is ``EchoEngine.confidence_fuse``)."""
-    fw = np.asarray(get_engine().cfg.FREQ_WEIGHTS)[band_idx]
-    snr = np.asarray(snr, dtype=np.float64); amplitude = np.asarray(amplitude, dtype=np.float64)
-    conf = np.minimum(snr / 10.0, 1.0) * 0.5 + np.minimum(amplitude / 0.1, 1.0) * 0.3 + fw * 0.2
-    return np.minimum(conf, 1.0)
+    """airSonar_optimized.py:222-243; scalars (the reference's call) or arrays of equal shape."""
+    e = get_engine()
+    scalar = np.ndim(snr) == 0 and not isinstance(snr, torch.Tensor)
+    like_np = _is_np(snr)
+    s = e._dev(np.asarray(snr, dtype=np.float64) if like_np else snr, torch.float64)
+    shape = tuple(s.shape)
+    a = e._dev(np.broadcast_to(np.asarray(amplitude, dtype=np.float64), shape).copy() if _is_np(amplitude) else amplitude,
+               torch.float64)
+    j = e._dev(np.broadcast_to(np.asarray(band_idx, dtype=np.int32), shape).copy() if _is_np(band_idx) else band_idx,
+               torch.int32)
+    out = e.band_confidence(s, a, j).reshape(shape)
+    if scalar:
+        return float(out)
+    return _ret(out, like_np)
 
 
-def normalize_confidences(confidences, valid=None):
-    """airSonar_optimized.py:245-262 over the last axis; ``valid`` masks bands that produced no range."""
-    c = np.array(confidences, dtype=np.float64)
-    if valid is None:
-        valid = np.ones_like(c, dtype=bool)
-    c = np.where(valid, c, 0.0)
-    total = c.sum(axis=-1, keepdims=True)
-    n = np.maximum(valid.sum(axis=-1, keepdims=True), 1)
-    return np.where(valid, np.where(total > 0, c / np.where(total > 0, total, 1.0) * 100.0, 100.0 / n), 0.0)
+def normalize_confidences(confidences):
+    """airSonar_optimized.py:245-262: the confidences of the valid bands of one frame (list / 1-D), or rows of
+    them [..., n]; each row is scaled to sum to 100."""
+    e = get_engine()
+    like_np = _is_np(confidences)
+    rows, lead = _rows(np.asarray(confidences, dtype=np.float64) if like_np else confidences, e, torch.float64,
+                       "normalize_confidences")
+    out = e.normalize_confidences(rows)
+    return _ret(out.reshape(lead + (out.shape[-1],)), like_np)
 
 
 class ScalarKalman:
-    """airSonar_optimized.py:265-283 with the same scalar interface, backed by a one-stream BatchedKalman."""
+    """airSonar_optimized.py:265-283 with the same scalar interface and defaults, backed by a one-stream
+    BatchedKalman (state in device memory)."""
 
-    def __init__(self, q=None, r=None):
-        e = get_engine()
-        if (q is not None and q != e.cfg.KALMAN_Q) or (r is not None and r != e.cfg.KALMAN_R):
-            raise ValueError("q/r differ from the engine's configuration")
-        self._k = BatchedKalman(e, 1)
+    def __init__(self, q=0.005, r=0.1):
+        self.q, self.r = q, r
+        self._k = BatchedKalman(get_engine(), 1, q=q, r=r)
 
     @property
     def x(self):
         return float(self._k.x[0]) if int(self._k.init[0]) else None
+
+    @property
+    def p(self):
+        return float(self._k.p[0])
 
     def update(self, z):
         return float(self._k.update(np.array([z], dtype=np.float64))[0])

@@ -12,7 +12,8 @@
  *   - Return value: 0 on success, negative ECHO_ERR_* otherwise; echo_strerror() names it.  Data-dependent
  *     "no echo" is not an error: peak_idx = -1, snr_db = 0, valid = 0 (reference: `return None, 0.0`).
  *   - A handle is immutable after echo_create except for its grow-only scratch; use one handle per
- *     device and do not issue overlapping calls on the same handle from different streams.
+ *     device and do not issue overlapping calls on the same handle from different streams.  A handle belongs to the
+ *     device that was current in echo_create: calls with another device current return ECHO_ERR_INVALID.
  */
 #ifndef ECHO_HIP_H
 #define ECHO_HIP_H
@@ -97,7 +98,8 @@ typedef struct EchoHandle EchoHandle;
  * Sizes: the spectra need an even n_rx (odd frame lengths run everything else).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
- * ECHO_ERR_UNSUPPORTED from echo_create: IIR order other than 6 or 8 (iir_ncoef 13 / 17), or a frame so long that one
+ * iir_ncoef = 1 with n_taps = 1 is the identity filter ([1], [1], [1]) design_filters falls back to (:178-182); zi may
+ * then be NULL.  ECHO_ERR_UNSUPPORTED from echo_create: IIR order other than 0, 6 or 8 (iir_ncoef 1 / 13 / 17), or a frame so long that one
  * frame's detector input exceeds a workgroup's 160 KB of LDS (about 20,000 lags). */
 int  echo_create(const EchoConfig* cfg, EchoHandle** out);
 void echo_destroy(EchoHandle* h);
@@ -119,12 +121,22 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
  * band_sig[B][nb][N] float64 -> spec[B][nb][N/2+1] float32.  db != 0: 20*log10(max(|X|,1e-12)); db == 0: |X|. */
 int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, int B, void* stream);
 
+/* gpu_spectrum on individual signals (airSonar_optimized.py:332-343; mag2db(np.fft.rfft(x)) :710 with db != 0):
+ * x[rows][N] float64, N the handle's frame length -> spec[rows][N/2+1] float32.  The transform does not depend on the
+ * band, so any number of rows is taken. */
+int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int rows, void* stream);
+
 /* gpu_mag2db / mag2db on an arbitrary array (airSonar_optimized.py:345-357). */
 int echo_mag2db(const float* x, float* out, size_t n, void* stream);
 
 /* gpu_correlate: scipy.signal.correlate(a, b, 'full') against the band's chirp
  * (airSonar_optimized.py:290-303).  band_sig[B][nb][N] -> corr[B][nb][N+M-1], float64. */
 int echo_correlate(EchoHandle* h, const double* band_sig, double* corr, int B, void* stream);
+
+/* gpu_correlate for arbitrary operands, as the reference calls it per band (airSonar_optimized.py:290-303, calls
+ * :639, :712): out[row][k] = scipy.signal.correlate(a[row], b, 'full')[k], a[rows][n], b[m], out[rows][n+m-1], float64,
+ * direct sums in the order of echo_correlate.  ECHO_ERR_UNSUPPORTED when b does not fit a workgroup's LDS (m > ~8000). */
+int echo_xcorr(const double* a, const double* b, double* out, int rows, int n, int m, void* stream);
 
 /* first_strong_peak (airSonar_optimized.py:200-219; variants per cfg.detector).  Mutates corr exactly as the
  * reference does (blind zone corr[half : half+min_delay] zeroed).  Also returns amplitude = max|corr| of the
@@ -144,6 +156,16 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
 int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope, int32_t* peak_idx, double* snr_db,
                             double* quality, int32_t* n_peaks, int32_t* peaks, int B, void* stream);
 
+/* gpu_envelope_detection(signal, 'hilbert', smooth_window) on arbitrary rows (airSonar_optimized.py:431-475), e.g. the
+ * band-signal call with smooth_window = 3 (:636, :708): x[rows][len] float64, len even; smooth_window odd, 1..9.
+ * Outputs as echo_envelope_detection, per row; peak_idx / snr_db apply `min_delay` the way :647-654 do (pass 0 when
+ * only envelope, peaks and quality are wanted).  Lengths whose half has a large prime factor (4282 = 2 * 2141) run the
+ * Hilbert transform as Bluestein convolutions.  ECHO_ERR_UNSUPPORTED: odd or very short len, even smooth_window, or a
+ * transform that does not fit one workgroup's LDS (len beyond about 4700).  Allocates its plan on first use. */
+int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_window, int min_delay, double* envelope,
+                       int32_t* peak_idx, double* snr_db, double* quality, int32_t* n_peaks, int32_t* peaks, int rows,
+                       void* stream);
+
 /* gpu_argmax (airSonar_optimized.py:359-368): first index of the maximum of each row of x[rows][n]. */
 int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream);
 
@@ -151,6 +173,20 @@ int echo_argmax(const double* x, int32_t* out, int rows, int n, void* stream);
  * (airSonar_optimized.py:222-262, :662-667, :733-738).  Inputs [B][nb]; outputs per frame. */
 int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* snr_db, const double* amplitude,
                          EchoResult* out, int B, void* stream);
+
+/* calculate_band_confidence elementwise (airSonar_optimized.py:222-243; realtime_sonar.py:393 when cfg.confidence is
+ * ECHO_CONF_RAW): conf[i] from snr_db[i], amplitude[i] and band_idx[i] (0..2, selects the frequency weight). */
+int echo_band_confidence(EchoHandle* h, const double* snr_db, const double* amplitude, const int32_t* band_idx,
+                         double* conf, int n, void* stream);
+
+/* normalize_confidences (airSonar_optimized.py:245-262) on rows of n confidences (the valid bands of a frame): each row
+ * scaled to sum to 100, or 100 / n each when its sum is not positive. */
+int echo_normalize_confidences(const double* conf, double* out, int rows, int n, void* stream);
+
+/* ScalarKalman(q, r).update with explicit noise parameters (airSonar_optimized.py:265-283); otherwise as
+ * echo_kalman_update, which uses the handle's configuration. */
+int echo_kalman_update_qr(double* x, double* p, uint8_t* init, const double* z, const uint8_t* valid, double* out,
+                          int S, int T, double q, double r, void* stream);
 
 /* ScalarKalman.update for S independent streams (airSonar_optimized.py:265-283): T time steps,
  * z[t*S + s]; streams whose valid[t*S+s] == 0 are skipped at that step (run() only updates when a band

@@ -231,6 +231,8 @@ extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* 
     std::vector<cpx<double>> roots, wn, wl;
     env_tables(p, roots, wn, wl);
     p.roots = roots.data(); p.wn = wn.data(); p.wl = wl.data();
+    std::vector<cpx<double>> bsw, bsb;
+    if (p.bs_m) { env_bs_tables(p, bsw, bsb); p.bs_w = bsw.data(); p.bs_bhat = bsb.data(); }
     p.corr = corr; p.env_out = env_out;
     std::vector<EnvRes> res((size_t)B * nb);
     p.res_out = res.data();

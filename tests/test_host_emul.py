@@ -263,6 +263,18 @@ def test_emulated_envelope_branch(emul, gold_default):
             want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
             assert (want, len(pk)) == (peak[f, b], npk[f, b])
             assert abs(qual - q[f, b]) <= 1e-9 and amp[f, b] == np.abs(corr[f, b]).max()
+    # the band-signal call gpu_envelope_detection(band_sig, 'hilbert', 3): N = 4282 = 2 * 2141 (prime), so the
+    # half-length transforms run as Bluestein convolutions; envelope, peaks and quality against SciPy
+    bs = np.ascontiguousarray(g["stage_band_sig"][:3])
+    Bb, _, N = bs.shape
+    envb = np.zeros_like(bs); pk = np.zeros((Bb, nb), np.int32); npkb = np.zeros((Bb, nb), np.int32)
+    snrb = np.zeros((Bb, nb)); ampb = np.zeros((Bb, nb)); qb = np.zeros((Bb, nb))
+    assert emul.emul_env(N, nb, 0, 3, _ptr(bs), Bb, _ptr(envb), _ptr(pk), _ptr(snrb), _ptr(ampb), _ptr(qb), _ptr(npkb)) == 0
+    for f in range(Bb):
+        for b in range(nb):
+            e, pks, qual = O.gpu_envelope_detection(bs[f, b], 3)
+            assert np.abs(envb[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
+            assert len(pks) == npkb[f, b] and abs(qual - qb[f, b]) <= 1e-9
     # signal_quality from the float32 spectrum kernel with the second Bluestein round
     emul.emul_spec_hilbert.argtypes = [I, I, I, I, P, P, P, I, P, P, I]
     band = np.ascontiguousarray(g["stage_band_sig"][:4].astype(np.float32))
