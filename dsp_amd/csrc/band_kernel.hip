@@ -122,6 +122,407 @@ __device__ __forceinline__ void bluestein9_round(int tid, const BandParams& p, u
     __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path of the fused chain (named mode, median detector): two kernels.
+//
+// band2_kernel, one 576-thread workgroup per (pair of frames, band), float32: FIR -> band_sig of both frames as the
+//   real and imaginary part of one complex signal (correlation with a real chirp is real-linear, so one complex
+//   4608-point cyclic convolution yields both correlations, every lag) -> float32 maxima (signed over
+//   pos[min_delay:], absolute over every lag outside the blind zone) and the list of lags whose float32 value lies
+//   within 2 eps of them, eps being a bound on the float32 path's error.
+// exact_kernel, one 256-thread workgroup per (frame, band), float64: the noise window and every listed lag, exactly:
+//   FIR outputs from the float64 y, then the chirp dot products, both as sequential fused multiply-add sums (the
+//   operation order of the single-frame kernel).  The true extrema are among the re-evaluated lags, so peak index,
+//   SNR and amplitude are those of an all-float64 evaluation and do not depend on the partner frame.
+// Reference: airSonar_optimized.py:193-194 (FIR), :290-303 (correlate), :200-219 (first_strong_peak), :666 (amplitude).
+
+// Block reduction of four values per thread (op 1: max, op 0: sum); every thread gets the four results.
+// `area` alternates between calls so that one barrier per call suffices.
+__device__ __forceinline__ void b2_reduce4(double (&v)[4], const int (&ops)[4], double* red, int area, int tid) {
+    constexpr int kWaves = kF9NT / 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double x = __shfl_xor(v[q], o);
+            v[q] = ops[q] ? (x > v[q] ? x : v[q]) : v[q] + x;
+        }
+    double* r = red + area * kWaves * 4;
+    if ((tid & 63) == 0)
+        for (int q = 0; q < 4; ++q) r[(tid >> 6) * 4 + q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double a = r[q];
+        for (int w = 1; w < kWaves; ++w) { const double x = r[w * 4 + q]; a = ops[q] ? (x > a ? x : a) : a + x; }
+        v[q] = a;
+    }
+}
+
+// An opaque copy of a per-lane value: index arithmetic derived from it cannot be hoisted above this point, which keeps
+// the addresses of a later phase out of the registers of an earlier one.
+#define ECHO_OPAQUE(x) asm volatile("" : "+v"(x))
+
+__global__ __launch_bounds__(kF9NT, 7) void band2_kernel(BandParams p, int B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    (void)blk;
+    const int band = blockIdx.x % p.nb, pair = blockIdx.x / p.nb;
+    STAMP(0);
+    const bool have1 = 2 * pair + 1 < B;
+    float2* fft = reinterpret_cast<float2*>(smem);
+    float* ybuf = reinterpret_cast<float*>(smem);                     // both frames' FIR inputs, inside the transform buffer
+    float* ct32 = reinterpret_cast<float*>(smem + p.b2_off_ct32);
+    double* red = reinterpret_cast<double*>(smem + p.b2_off_red);
+    int* ncand = reinterpret_cast<int*>(smem + p.b2_off_misc);        // [2]
+    const int kstart = p.half + p.min_delay;
+    {
+        const int nt_ = (p.kgroups + 1) * kR;
+        for (int i = tid; i < nt_; i += kF9NT) ct32[i] = (float)p.taps_rev[(size_t)band * nt_ + i];
+        if (tid < 2) ncand[tid] = 0;
+    }
+    // ---- y of both frames, rounded to float32, into LDS: frame f at ybuf + f * ybuf_len
+    double ymax = 0.0;
+    {
+        const double* y0 = p.d_in + ((size_t)(2 * pair) * p.nb + band) * p.N;
+        const double* y1 = y0 + (size_t)p.nb * p.N;
+        constexpr int kBatch = 16;                           // 2 * ybuf_len <= 16 * 576 for the frame lengths this kernel takes: one round trip
+        const int total = 2 * p.ybuf_len;
+        for (int i0 = tid; i0 < total; i0 += kBatch * kF9NT) {
+            double t[kBatch];
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e) {
+                const int i = i0 + e * kF9NT;
+                const int f = i >= p.ybuf_len ? 1 : 0, n = i - f * p.ybuf_len - p.ypad;
+                t[e] = (i < total && n >= 0 && n < p.N && (f == 0 || have1)) ? (f ? y1 : y0)[n] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e)
+                if (i0 + e * kF9NT < total) {
+                    ybuf[i0 + e * kF9NT] = (float)t[e];
+                    const double a = fabs(t[e]); ymax = a > ymax ? a : ymax;
+                }
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---- float32 FIR of both frames
+    float acc[2][kR];
+    {
+        const int n0 = tid * kR;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (n0 < p.N) sliding_dot_ff(ybuf + f * p.ybuf_len + n0, ct32, p.kgroups, acc[f]);
+            else {
+#pragma unroll
+                for (int r = 0; r < kR; ++r) acc[f][r] = 0.f;
+            }
+        }
+    }
+    __syncthreads();                                       // every lane has read its inputs: the buffer may be overwritten
+    ECHO_OPAQUE(tid);
+    STAMP(2);
+    // ---- x[n] = band_sig_A[n] + i band_sig_B[n] into the transform buffer
+    double ss = 0.0;
+    {
+        const int n0 = tid * kR;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int n = n0 + r;
+            if (n >= kF9M) continue;
+            const bool in = n < p.N;
+            const float a = in ? acc[0][r] : 0.f, b = in ? acc[1][r] : 0.f;
+            fft[pos9(n)] = mk2(a, b);
+            ss += (double)a * (double)a + (double)b * (double)b;
+        }
+    }
+    double eps;
+    {
+        double r4[4] = {ymax, ss, 0.0, 0.0};
+        const int ops[4] = {1, 0, 0, 0};
+        b2_reduce4(r4, ops, red, 0, tid);                  // its barrier also publishes the transform input
+        eps = p.eps_fir[band] * r4[0] + p.eps_fft[band] * sqrt(r4[1]);
+    }
+    ECHO_OPAQUE(tid);
+    // float32 band signals to the spectrum kernel, read back from the buffer so that consecutive lanes store
+    // consecutive samples
+    if (p.bandf_out) {
+        float* o0 = p.bandf_out + ((size_t)(2 * pair) * p.nb + band) * p.N;
+        float* o1 = o0 + (size_t)p.nb * p.N;
+        for (int n = tid; n < p.N; n += kF9NT) {
+            const float2 x = fft[pos9(n)];
+            o0[n] = x.x;
+            if (have1) o1[n] = x.y;
+        }
+        __syncthreads();                                   // the transform overwrites the buffer in place
+    }
+    // ---- cyclic convolution with the reversed chirp: corr_A + i corr_B, every lag; the last inverse pass leaves its
+    // outputs (lags tid + 512 j) in registers, where the maxima are taken
+    ECHO_OPAQUE(tid);
+    STAMP(3);
+    float2 cv[9];
+    {
+        BandParams q = p;
+        q.off_fft = 0; q.f9bhat = p.f9ghat + (size_t)band * kF9M;
+        ph9_r9<false>(tid, q, smem);
+        __syncthreads();
+        ph9_r8<false>(tid, 64, q, smem);
+        __syncthreads();
+        ph9_r8<false>(tid, 8, q, smem);
+        __syncthreads();
+        ph9_mid(tid, q, smem);
+        __syncthreads();
+        ph9_r8<true>(tid, 8, q, smem);
+        __syncthreads();
+        ph9_r8<true>(tid, 64, q, smem);
+        __syncthreads();
+        ph9_r9_inv_regs(tid, q, smem, cv);
+    }
+    STAMP(4);
+    // ---- float32 maxima, then the lags that can hold the true ones
+    float mx[2] = {-INFINITY, -INFINITY}, am[2] = {0.f, 0.f};
+    if (tid < 512) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = tid + 512 * j, qd = k - p.half;
+            if (k >= p.L || (qd >= 0 && qd < p.min_delay)) continue;     // beyond the last lag; blind zone: zero by definition
+            am[0] = fmaxf(am[0], fabsf(cv[j].x)); am[1] = fmaxf(am[1], fabsf(cv[j].y));
+            if (k >= kstart) { mx[0] = fmaxf(mx[0], cv[j].x); mx[1] = fmaxf(mx[1], cv[j].y); }
+        }
+    }
+    {
+        double r4[4] = {(double)mx[0], (double)mx[1], (double)am[0], (double)am[1]};
+        const int ops[4] = {1, 1, 1, 1};
+        b2_reduce4(r4, ops, red, 1, tid);
+        // thresholds in float32, rounded down
+        const double e2 = 2.0 * eps;
+        mx[0] = __double2float_rd(r4[0] - e2); mx[1] = __double2float_rd(r4[1] - e2);
+        am[0] = __double2float_rd(r4[2] - e2); am[1] = __double2float_rd(r4[3] - e2);
+        if (tid < 2 && (tid == 0 || have1)) {
+            B2Det* d = p.det_out + ((size_t)(2 * pair + tid) * p.nb + band);
+            d->eps = eps; d->max32 = (float)r4[tid]; d->amp32 = (float)r4[2 + tid];
+        }
+    }
+    const int nz_lo = kstart, nz_hi = kstart + p.noise_n;   // evaluated exactly anyway
+    if (tid < 512) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = tid + 512 * j, qd = k - p.half;
+            if (k >= p.L || (qd >= 0 && qd < p.min_delay)) continue;
+            if (k >= nz_lo && k < nz_hi) continue;
+            const float2 c = cv[j];
+            const bool c0 = (k >= kstart && c.x >= mx[0]) || fabsf(c.x) >= am[0];
+            const bool c1 = have1 && ((k >= kstart && c.y >= mx[1]) || fabsf(c.y) >= am[1]);
+            if (c0) { const int slot = atomicAdd(&ncand[0], 1); if (slot < kB2MaxCand) p.det_out[(size_t)(2 * pair) * p.nb + band].cand[slot] = k; }
+            if (c1) { const int slot = atomicAdd(&ncand[1], 1); if (slot < kB2MaxCand) p.det_out[(size_t)(2 * pair + 1) * p.nb + band].cand[slot] = k; }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 && (tid == 0 || have1)) p.det_out[(size_t)(2 * pair + tid) * p.nb + band].ncand = ncand[tid];
+    STAMP(5);
+}
+
+// Exact float64 evaluation of one segment of lags [k0, k0 + nl) of one (frame, band): stage y, FIR -> band_sig window
+// (zero outside [0, N), as the 'same' crop leaves it), chirp dot products, fold into the running maximum (first index
+// on ties), the amplitude and the noise window.  Called by all 256 threads; returns after a barrier.
+constexpr int kExNT = 256;
+struct ExView { const double *gt64, *gc64; double *yw, *bw, *cv, *nw; float* nwf; int* cnt; B2Misc* misc; };
+
+// acc[r] = sum_j x[r + j] * c[j], j < n rounded up to a multiple of T (c is zero beyond n, x finite), as sequential
+// fused multiply-add sums in ascending j.  x: LDS window, read in batches of R + T - 1 samples for R * T multiply-adds
+// (the LDS, shared by the four SIMDs of a compute unit, is what this kernel would otherwise be bound by); c: the
+// coefficient table in device memory, indexed uniformly across the wavefront (scalar loads).
+template <int R, int T> __device__ __forceinline__ void ex_dots(const double* x, const double* __restrict__ c, int n,
+                                                                  double (&acc)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < n; j += T) {
+        double xv[R + T - 1], cc[T];
+#pragma unroll
+        for (int t = 0; t < R + T - 1; ++t) xv[t] = x[j + t];
+#pragma unroll
+        for (int t = 0; t < T; ++t) cc[t] = c[j + t];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(xv[r + t], cc[t], acc[r]);
+    }
+}
+
+// RF / RC: consecutive FIR outputs / lags per lane (sliding dot products: one LDS read of the signal per RF or RC
+// multiply-adds).  Long segments take 9 of each -- least LDS traffic, which is what bounds this kernel; segments of a
+// few lags take short chains on more lanes.  The summation order per output is the same for every RF / RC.
+template <int RF, int RC, int SLOT = 0>
+__device__ __forceinline__ void exact_segment(const BandParams& p, const ExView& v, const double* y, int k0, int nl,
+                                              int tid) {
+    const int blk = blockIdx.x; (void)blk;
+    const int kstart = p.half + p.min_delay;
+    const int nb0 = k0 - (p.M - 1);                          // band_sig index of window element 0
+    const int nband = nl + p.M - 1;
+    const int nfir = (nband + RF - 1) / RF, ncl = (nl + RC - 1) / RC;
+    for (int i = tid; i < p.b2_ywlen; i += kExNT) {
+        const int n = nb0 - p.ypad + i;
+        v.yw[i] = (n >= 0 && n < p.N) ? y[n] : 0.0;
+    }
+    __syncthreads();
+    if (SLOT) STAMP(SLOT);
+    for (int l = tid; l < nfir; l += kExNT) {
+        double a[RF];
+        ex_dots<RF, 8>(v.yw + RF * l, v.gt64, p.K, a);
+#pragma unroll
+        for (int r = 0; r < RF; ++r) { const int n = nb0 + RF * l + r; v.bw[RF * l + r] = (n >= 0 && n < p.N) ? a[r] : 0.0; }
+    }
+    for (int i = RF * nfir + tid; i < p.b2_bwlen; i += kExNT) v.bw[i] = 0.0;
+    __syncthreads();
+    if (SLOT) STAMP(SLOT + 1);
+    for (int l = tid; l < ncl; l += kExNT) {
+        double a[RC];
+        ex_dots<RC, 8>(v.bw + RC * l, v.gc64, p.M, a);
+#pragma unroll
+        for (int r = 0; r < RC; ++r) if (RC * l + r < nl) v.cv[RC * l + r] = a[r];
+    }
+    __syncthreads();
+    if (SLOT) STAMP(SLOT + 2);
+    if (tid < 64) {
+        double best = -INFINITY, amp = 0.0; int bidx = 0x7fffffff;
+        for (int i = tid; i < nl; i += 64) {
+            const int k = k0 + i, qd = k - p.half;
+            if (qd >= 0 && qd < p.min_delay) continue;
+            const double x = v.cv[i], a = fabs(x);
+            amp = a > amp ? a : amp;
+            if (k >= kstart) {
+                if (x > best) { best = x; bidx = qd; }
+                const int w = qd - p.min_delay;
+                if (w < p.noise_n) { v.nw[w] = a; v.nwf[w] = (float)a; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o); const int i2 = __shfl_xor(bidx, o);
+            combine(best, bidx, b2, i2);
+            const double a2 = __shfl_xor(amp, o); amp = a2 > amp ? a2 : amp;
+        }
+        if (tid == 0) {
+            double mb = v.misc->best; int mi = v.misc->bidx;
+            combine(mb, mi, best, bidx);
+            v.misc->best = mb; v.misc->bidx = mi;
+            v.misc->amp = amp > v.misc->amp ? amp : v.misc->amp;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kExNT, 6) void exact_kernel(BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x, band = blk % p.nb;
+    STAMP(12);
+    ExView v;
+    {
+        double* d = reinterpret_cast<double*>(smem);
+        const int nt_ = (p.kgroups + 1) * kR, nc_ = (p.mgroups + 1) * kR, nn = p.noise_n;
+        v.gt64 = p.taps_rev + (size_t)band * nt_; v.gc64 = p.chirp + (size_t)band * nc_;
+        v.yw = d; d += p.b2_ywlen; v.bw = d; d += p.b2_bwlen; v.cv = d; d += (kB2Seg + 1) & ~1;
+        v.nw = d; d += nn; v.nwf = reinterpret_cast<float*>(d); d += (nn + 1) / 2;
+        v.cnt = reinterpret_cast<int*>(d); d += nn;
+        v.misc = reinterpret_cast<B2Misc*>(d);
+        if (tid == 0) {
+            v.misc->best = p.min_delay > 0 ? 0.0 : -INFINITY; v.misc->bidx = p.min_delay > 0 ? 0 : 0x7fffffff;   // pos[0] = 0 in the blind zone
+            v.misc->amp = 0.0; v.misc->med0 = 0.0; v.misc->med1 = 0.0;
+        }
+    }
+    const double* y = p.d_in + (size_t)blk * p.N;
+    // the listed lags, read once: lane i of every wavefront holds entry i
+    const B2Det* det = p.det_out + blk;
+    const int nc = det->ncand;
+    const int lane = tid & 63;
+    const int mine = (lane < nc && lane < kB2MaxCand) ? det->cand[lane] : 0x7fffffff;
+    // the noise window, then the listed lags (segments that start at a listed lag cover the listed lags behind it);
+    // an overflowing list means nothing is known, and every lag is evaluated
+    STAMP(13);
+    exact_segment<9, 4, 17>(p, v, y, p.half + p.min_delay, p.noise_n, tid);      // its first barrier publishes the tables
+    STAMP(14);
+    if (nc > kB2MaxCand) {
+        for (int k0 = 0; k0 < p.L; k0 += kB2Seg) exact_segment<9, 4>(p, v, y, k0, p.L - k0 < kB2Seg ? p.L - k0 : kB2Seg, tid);
+    } else {
+        int done_below = 0;                                    // lags below it have been evaluated
+        for (;;) {
+            int lo = mine >= done_below ? mine : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(lo, o); lo = x < lo ? x : lo; }
+            if (lo == 0x7fffffff) break;
+            // how far the listed lags reach from lo inside one segment
+            int hi = (mine >= lo && mine < lo + kB2Seg) ? mine : lo;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(hi, o); hi = x > hi ? x : hi; }
+            if (hi - lo >= 16) exact_segment<9, 4>(p, v, y, lo, hi - lo + 1, tid);
+            else exact_segment<5, 1>(p, v, y, lo, hi - lo + 1, tid);
+            done_below = hi + 1;
+        }
+    }
+    // ---- median of the noise window (np.median: mean of the two middle order statistics): the first wavefront sorts
+    // the window, padded with +inf to 256 values, four per lane, by a bitonic network in registers
+    STAMP(15);
+    const int n = p.noise_n;
+    if (tid < 64) {
+        double x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = tid * 4 + e; x[e] = i < n ? v.nw[i] : INFINITY; }
+#pragma unroll
+        for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = tid * 4 + e;
+                        const double o = __shfl_xor(x[e], j >> 2);
+                        const bool lower = (i & j) == 0, asc = (i & k) == 0;
+                        const double mn = fmin(x[e], o), mx = fmax(x[e], o);
+                        x[e] = (lower == asc) ? mn : mx;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e & j) continue;
+                        const int i = tid * 4 + e;
+                        const bool asc = (i & k) == 0;
+                        const double a = x[e], b = x[e | j];
+                        const double mn = fmin(a, b), mx = fmax(a, b);
+                        x[e] = asc ? mn : mx; x[e | j] = asc ? mx : mn;
+                    }
+                }
+            }
+        }
+        // ranks (n - 1) / 2 and n / 2 of the sorted sequence
+        const int r0 = (n - 1) / 2, r1 = n / 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid * 4 + e;
+            if (i == r0) v.misc->med0 = x[e];
+            if (i == r1) v.misc->med1 = x[e];
+        }
+    }
+    __syncthreads();
+    STAMP(16);
+    // ---- SNR, gate, record (first_strong_peak, airSonar_optimized.py:209-219)
+    if (tid == 0 && p.res_out) {
+        const B2Misc* m = v.misc;
+        BandRes r;
+        r.amplitude = m->amp; r.pad = 0;
+        const double med = (m->med0 + m->med1) / 2.0, noise_floor = med * med;
+        const double peak_power = m->best * m->best;
+        double snr = 0.0;
+        if (noise_floor > 0.0) snr = 10.0 * log10(peak_power / noise_floor);
+        if (snr < p.snr_gate) { r.peak_idx = -1; r.snr_db = 0.0; }
+        else                  { r.peak_idx = m->bidx; r.snr_db = snr; }
+        p.res_out[blk] = r;
+    }
+}
+
+
 __global__ __launch_bounds__(kF9NT) void spec9_kernel(BandParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
@@ -196,6 +597,27 @@ int band_kernel_prepare(int smem_bytes, int spec_smem_bytes, int spec_hilb_smem_
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(spec9_hilbert_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, spec_hilb_smem_bytes);
     return e == hipSuccess ? 0 : -4;
+}
+
+int band2_kernel_prepare(int smem_bytes, int exact_smem_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(band2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem_bytes) != hipSuccess) return -4;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               exact_smem_bytes) == hipSuccess ? 0 : -4;
+}
+
+int launch_band2_pair(const BandParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!p.band2 || !p.d_in || !p.f9ghat || !p.det_out) return -1;
+    hipLaunchKernelGGL(band2_kernel, dim3((unsigned)((B + 1) / 2) * p.nb), dim3(kF9NT), p.b2_smem_bytes, s, p, B);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_band2_exact(const BandParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!p.band2 || !p.d_in || !p.res_out || !p.det_out) return -1;
+    hipLaunchKernelGGL(exact_kernel, dim3((unsigned)B * p.nb), dim3(kExNT), p.b2_exact_smem_bytes, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int launch_spec(const BandParams& p, int B, hipStream_t s) {

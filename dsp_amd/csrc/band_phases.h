@@ -35,6 +35,8 @@ typedef const double* lds_cptr_t;
 
 namespace echo {
 
+struct B2Det;
+
 constexpr int kR = 9;          // consecutive outputs per lane in the sliding dot products
 constexpr int kFftM = 8192;    // Bluestein cyclic length (>= 2*(N/2)-1), 8*8*8*4*4
 constexpr int kNT = 512;       // threads per workgroup of the band kernel
@@ -102,6 +104,16 @@ struct BandParams {
     int spec_hilb_smem_bytes;        // LDS of the spectrum kernel with the envelope branch
     double* sq_out;                  // [B][nb] signal_quality (envelope branch; null = spectrum only)
     int write_corr_mutated;          // MODE_CORR: write the zeroed blind zone back
+    // Pair kernel of the chain (band2_kernel): float32 FFT matched filter over all lags, exact float64 re-evaluation
+    // of the noise window and of every lag that can be the maximum
+    int band2;                       // configuration fits the pair kernel
+    const float2* f9ghat;            // [nb][4608] FFT of the reversed chirp / 4608, pass order of the 4608-point transform
+    double eps_fir[3];               // per band: bound on the float32 FIR's contribution to a lag's error, per unit max|y|
+    double eps_fft[3];               // per band: bound on the float32 transforms' contribution, per unit ||band_sig pair||_2
+    int b2_off_ct32, b2_off_red, b2_off_misc, b2_smem_bytes;   // LDS of the pair kernel behind the transform buffer
+    int b2_ywlen, b2_bwlen;          // exact kernel: doubles of the y and band_sig windows of one segment
+    int b2_exact_smem_bytes;
+    struct B2Det* det_out;           // [B][nb] float32 maxima and candidate lags, pair kernel -> exact kernel
 };
 
 struct Misc {                        // lives at off_misc
@@ -151,6 +163,60 @@ ECHO_HD void sliding_dot(const double* in, const double* c, int ngroups, double 
         dot_block(w, c1, in + (g + 2) * kR, acc);
     }
     if (g < ngroups) dot_block(w, c0, in + (g + 1) * kR, acc);
+}
+
+// The same sliding dot with R consecutive outputs per lane (R independent accumulation chains): identical operation
+// order per output, hence identical bits, for any R.  c must be zero-padded to (ngroups + 1) * R entries, `in` readable
+// up to index (ngroups + 1) * R - 1.
+template <int R> ECHO_HD void dot_block_r(double (&w)[R], const double (&c)[R], const double* nx, double (&acc)[R]) {
+    lds_cptr_t vx = ECHO_LDS_CPTR(nx);
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fma(w[(r + t) % R], c[t], acc[r]);
+        w[t] = vx[t];
+    }
+}
+template <int R> ECHO_HD void sliding_dot_r(const double* in, const double* c, int ngroups, double (&acc)[R]) {
+    double w[R], c0[R], c1[R];
+    lds_cptr_t vc = ECHO_LDS_CPTR(c);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { w[r] = in[r]; c0[r] = c[r]; acc[r] = 0.0; }
+    int g = 0;
+    for (; g + 1 < ngroups; g += 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) c1[r] = vc[(g + 1) * R + r];
+        dot_block_r<R>(w, c0, in + (g + 1) * R, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) c0[r] = vc[(g + 2) * R + r];
+        dot_block_r<R>(w, c1, in + (g + 2) * R, acc);
+    }
+    if (g < ngroups) dot_block_r<R>(w, c0, in + (g + 1) * R, acc);
+}
+
+// float32 signal and coefficients (the pair kernel's FIR)
+ECHO_HD void dot_block_ff(float (&w)[kR], const float (&c)[kR], const float* nx, float (&acc)[kR]) {
+#pragma unroll
+    for (int t = 0; t < kR; ++t) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) acc[r] = fmaf(w[(r + t) % kR], c[t], acc[r]);
+        w[t] = nx[t];
+    }
+}
+ECHO_HD void sliding_dot_ff(const float* in, const float* c, int ngroups, float (&acc)[kR]) {
+    float w[kR], c0[kR], c1[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { w[r] = in[r]; c0[r] = c[r]; acc[r] = 0.f; }
+    int g = 0;
+    for (; g + 1 < ngroups; g += 2) {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c1[r] = c[(g + 1) * kR + r];
+        dot_block_ff(w, c0, in + (g + 1) * kR, acc);
+#pragma unroll
+        for (int r = 0; r < kR; ++r) c0[r] = c[(g + 2) * kR + r];
+        dot_block_ff(w, c1, in + (g + 2) * kR, acc);
+    }
+    if (g < ngroups) dot_block_ff(w, c0, in + (g + 1) * kR, acc);
 }
 
 // float32 variant: the window comes from the float64 LDS signal (converted on load), coefficients from a float copy.

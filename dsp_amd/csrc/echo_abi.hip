@@ -26,6 +26,7 @@ struct Scratch {
     double* fused = nullptr;
     uint8_t* vany = nullptr;
     EnvRes* env = nullptr;                 // envelope-branch results, [frames][nb]
+    B2Det* det = nullptr;                  // pair kernel -> exact kernel: float32 maxima and candidate lags, [frames][nb]
 };
 
 // Scratch of echo_chain_noalloc: one array per GPU (every device that loads the library holds its own copy at its own
@@ -71,7 +72,8 @@ struct EchoHandle {
     // device constant tables
     double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
     float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
-    float2 *d_f9tw9 = nullptr, *d_f9twa = nullptr, *d_f9twb = nullptr, *d_f9bhat = nullptr;
+    float2 *d_f9tw9 = nullptr, *d_f9twa = nullptr, *d_f9twb = nullptr, *d_f9bhat = nullptr, *d_f9ghat = nullptr;
+    int use_band2 = 1;                     // ECHO_BAND2=0: the named chain keeps the single-frame band kernel
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
@@ -105,7 +107,7 @@ template <class T> int dev_upload(T** dst, const T* src, size_t n) {
 void free_scratch(EchoHandle* h) {
     (void)hipFree(h->sc.fwd); (void)hipFree(h->sc.y); (void)hipFree(h->sc.res); (void)hipFree(h->sc.fused);
     (void)hipFree(h->sc.vany); (void)hipFree(h->sc.bandf); (void)hipFree(h->sc.band); (void)hipFree(h->sc.pos);
-    (void)hipFree(h->sc.env); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
+    (void)hipFree(h->sc.env); (void)hipFree(h->sc.det); (void)hipFree(h->d_corr); (void)hipFree(h->d_sq); (void)hipFree(h->d_spec);
     h->sc = Scratch();
     h->d_corr = nullptr; h->d_sq = nullptr; h->d_spec = nullptr;
     h->cap_full = 0;
@@ -113,7 +115,7 @@ void free_scratch(EchoHandle* h) {
 }
 
 // Elements per frame-batch of each scratch buffer (shared by the allocating and the carving path).
-struct ScratchSizes { size_t fwd, y, bandf, band, pos, res, fused, vany, env; };
+struct ScratchSizes { size_t fwd, y, bandf, band, pos, res, fused, vany, env, det; };
 ScratchSizes scratch_sizes(const EchoHandle* h, int frames) {
     const EchoConfig& c = h->cfg;
     const int P = 3 * c.iir_ncoef;
@@ -129,6 +131,7 @@ ScratchSizes scratch_sizes(const EchoHandle* h, int frames) {
     z.fused = (size_t)frames * sizeof(double);
     z.vany = (size_t)frames;
     z.env = (size_t)frames * c.n_bands * sizeof(EnvRes);
+    z.det = h->base.band2 ? (size_t)frames * c.n_bands * sizeof(B2Det) : 0;
     return z;
 }
 
@@ -151,6 +154,7 @@ bool carve_scratch(const EchoHandle* h, int frames, unsigned char* base, size_t 
     sc.fused = reinterpret_cast<double*>(take(z.fused));
     sc.vany = reinterpret_cast<uint8_t*>(take(z.vany));
     sc.env = reinterpret_cast<EnvRes*>(take(z.env));
+    sc.det = reinterpret_cast<B2Det*>(take(z.det));
     return off <= bytes;
 }
 
@@ -162,7 +166,7 @@ int ensure_scratch(EchoHandle* h, int frames) {
     auto get = [](auto** p, size_t n) { return n == 0 || hipMalloc(reinterpret_cast<void**>(p), n) == hipSuccess; };
     if (!get(&h->sc.fwd, z.fwd) || !get(&h->sc.y, z.y) || !get(&h->sc.bandf, z.bandf) || !get(&h->sc.band, z.band) ||
         !get(&h->sc.pos, z.pos) || !get(&h->sc.res, z.res) || !get(&h->sc.fused, z.fused) ||
-        !get(&h->sc.env, z.env) || !get(&h->sc.vany, z.vany)) {
+        !get(&h->sc.env, z.env) || !get(&h->sc.vany, z.vany) || !get(&h->sc.det, z.det)) {
         free_scratch(h);
         return ECHO_ERR_NOMEM;
     }
@@ -365,8 +369,13 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     for (int j = 0; j < nb; ++j)
         if (cfg->a[j * nc] != 1.0) { delete h; return ECHO_ERR_INVALID; }   // tables must be a0-normalised
     HostTables t;
+    if (const char* m = std::getenv("ECHO_BAND2")) h->use_band2 = std::atoi(m);       // development override
+    if (!h->base.fft9 || !h->use_band2) h->base.band2 = 0;
     if (h->long_path) build_coef_tables(t, nb, cfg->n_taps, cfg->n_chirp, cfg->taps, cfg->chirps);
-    else build_tables(t, h->base, cfg->taps, cfg->chirps);
+    else {
+        build_tables(t, h->base, cfg->taps, cfg->chirps);
+        if (h->base.band2) band2_bounds(h->base, cfg->taps, cfg->chirps);
+    }
     int rc = ECHO_OK;
     auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
     up(dev_upload(&h->d_b, cfg->b, (size_t)nb * nc));
@@ -385,6 +394,10 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_f9twa, t.f9twa.data(), t.f9twa.size()));
             up(dev_upload(&h->d_f9twb, t.f9twb.data(), t.f9twb.size()));
             up(dev_upload(&h->d_f9bhat, t.f9bhat.data(), t.f9bhat.size()));
+        }
+        if (h->base.band2) {
+            up(dev_upload(&h->d_f9ghat, t.f9ghat.data(), t.f9ghat.size()));
+            if (rc == ECHO_OK) rc = band2_kernel_prepare(h->base.b2_smem_bytes, h->base.b2_exact_smem_bytes);
         }
         if (const char* pad = std::getenv("ECHO_BAND_SMEM_PAD")) h->base.smem_bytes += std::atoi(pad);   // development: occupancy experiments
         if (const char* f9 = std::getenv("ECHO_FFT9")) h->base.fft9 = h->base.fft9 && std::atoi(f9) != 0;   // development override
@@ -437,6 +450,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
     h->base.uk = h->d_uk;
     h->base.f9tw9 = h->d_f9tw9; h->base.f9twa = h->d_f9twa; h->base.f9twb = h->d_f9twb; h->base.f9bhat = h->d_f9bhat;
+    h->base.f9ghat = h->d_f9ghat;
     h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
@@ -449,7 +463,7 @@ void echo_destroy(EchoHandle* h) {
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
-                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_cfg, h->d_cfw2, h->d_cftw};
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
@@ -900,10 +914,16 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 1;
             p.d_in = y_in; p.res_out = sc.res;
             p.bandf_out = spec_db ? sc.bandf : nullptr;
-            rc = launch_band(p, n, s);
+            p.det_out = sc.det;
+            if (!p.band2) rc = launch_band(p, n, s);
+            else {
+                rc = launch_band2_pair(p, n, s);
+                if (rc) return rc;
+                rc = launch_band2_exact(p, n, s);
+            }
             if (rc) return rc;
         }
-        if (pre) {                                         // the band kernel was the last reader of the prefetched IIR output
+        if (pre) {                                         // the band kernels were the last readers of the prefetched IIR output
             if (hipEventRecord(h->pf_consumed[pre_slot], s) != hipSuccess) return ECHO_ERR_HIP;
             h->pf_consumed_set[pre_slot] = true;
         }

@@ -49,6 +49,9 @@ int iir_kernel_prepare();                                                       
 int launch_iir_quad(const IirParams& p, int ncoef, int lps, hipStream_t s);    // lps lanes per (frame, band): 4 or 16; tiles of 64/lps frames
 int launch_band(const BandParams& p, int B, hipStream_t s);
 int band_kernel_prepare(int smem_bytes, int spec_smem_bytes, int spec_hilb_smem_bytes);
+int band2_kernel_prepare(int smem_bytes, int exact_smem_bytes);
+int launch_band2_pair(const BandParams& p, int B, hipStream_t s);     // chain fast path: float32 matched filter, pairs of frames per workgroup
+int launch_band2_exact(const BandParams& p, int B, hipStream_t s);    // chain fast path: exact float64 re-evaluation, one workgroup per (frame, band)
 int launch_spec(const BandParams& p, int B, hipStream_t s);
 int launch_spec_hilbert(const BandParams& p, int B, hipStream_t s);   // spectrum + signal_quality of the band signal
 int long_kernels_prepare(const LongParams& p);

@@ -19,6 +19,21 @@ constexpr int kF9Slots = kF9M + kF9M / 8;          // 5184 float2 = 41472 bytes
 
 ECHO_HD int pos9(int e) { return e + (e >> 3); }
 
+// Pair kernel (band2_kernel): sizes shared by the kernel and the host-side plan
+constexpr int kB2R = 3;                 // lags (or FIR outputs) per lane in the exact float64 rounds
+constexpr int kB2Seg = 243;             // lags per exact segment: 81 lanes x 3
+constexpr int kB2MaxCand = 30;          // lags listed for exact evaluation per frame; beyond it every lag is evaluated
+struct B2Misc {                         // exact kernel: running results of one (frame, band), in LDS
+    double best, amp, med0, med1;
+    int bidx, pad;
+};
+struct B2Det {                          // pair kernel -> exact kernel, per (frame, band), in device memory
+    double eps;                         // bound on |float32 lag - exact lag|
+    float max32, amp32;                 // float32 maxima (signed over pos[min_delay:], absolute over every lag)
+    int ncand, pad;                     // lags listed; beyond kB2MaxCand the list is incomplete
+    int cand[kB2MaxCand];
+};
+
 // frequency index held at position p after the forward passes
 inline int pass_order_freq9(int p) {
     const int m1 = p / 512, m2 = (p / 64) % 8, m3 = (p / 8) % 8, m4 = p % 8;
@@ -92,6 +107,24 @@ template <bool INV> ECHO_HD void ph9_r9(int tid, const BandParams& p, unsigned c
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) f[pos9(tid + 512 * j)] = v[j];
+}
+
+// the last inverse pass with its outputs left in registers: v[j] is element tid + 512 j of the result (tid < 512)
+ECHO_HD void ph9_r9_inv_regs(int tid, const BandParams& p, unsigned char* smem, float2 (&v)[9]) {
+    if (tid >= 512) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] = mk2(0.f, 0.f);
+        return;
+    }
+    const float2* f = lds_c(smem, p.off_fft);
+    float2 w[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w[m] = p.f9tw9[m * 512 + tid];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = f[pos9(tid + 512 * j)];
+#pragma unroll
+    for (int m = 1; m < 9; ++m) v[m] = cmulc(v[m], w[m - 1]);
+    dft9<true>(v);
 }
 
 // radix-8 pass with stride q (64 or 8) inside each 512-block; twiddles tw[0..q) = W, tw[q..2q) = W^2, tw[2q..3q) = W^4,

@@ -1,6 +1,7 @@
 // Host-side construction of the constant tables and the LDS layout of the band kernel.
 // Plain C++ (no HIP): shared by the library's echo_create and by the host emulation used in unit tests.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -15,7 +16,7 @@ namespace echo {
 struct HostTables {
     std::vector<double> taps_rev;   // [nb][kgroups*kR]
     std::vector<double> chirp;      // [nb][mgroups*kR]
-    std::vector<float2> bw, bhat, tw, post, uk, f9tw9, f9twa, f9twb, f9bhat;
+    std::vector<float2> bw, bhat, tw, post, uk, f9tw9, f9twa, f9twb, f9bhat, f9ghat;
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -142,6 +143,27 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.fft9 = (2 * p.n2 - 1 <= kF9M) ? 1 : 0;
     p.spec_smem_bytes = p.fft9 ? kF9Slots * 8 : kFftM * 8;
     p.spec_hilb_smem_bytes = kFftM * 8;                      // envelope and scratch arrays sit behind the transform
+    // Pair kernel + exact kernel: median detector, every lag inside one 4608-point cyclic convolution, both frames'
+    // float32 FIR inputs inside the transform's buffer
+    {
+        const int kg3 = ceil_div(K, kB2R), mg3 = ceil_div(M, kB2R);
+        const int nband = kB2Seg + M - 1;                                  // band_sig samples one segment reads
+        p.b2_ywlen = align_up(nband + 16 + (p.kgroups + 1) * kR, 2);      // what up to 9 outputs per lane in batches of 8 taps read
+        p.b2_bwlen = align_up(kB2Seg + 16 + (p.mgroups + 1) * kR, 2);
+        (void)kg3; (void)mg3;
+        int o = kF9Slots * 8;
+        p.b2_off_ct32 = o; o += align_up((p.kgroups + 1) * kR * 4, 16);
+        p.b2_off_red = o;  o += 2 * (kF9NT / 64) * 4 * 8;
+        p.b2_off_misc = o; o += 16;
+        p.b2_smem_bytes = o;
+        const int nn1 = nn > 0 ? nn : 1;
+        p.b2_exact_smem_bytes = 8 * (p.b2_ywlen + p.b2_bwlen +
+                                     align_up(kB2Seg, 2) + nn1 + (nn1 + 1) / 2 + nn1) + align_up((int)sizeof(B2Misc), 16);
+        const bool fits = detector == 0 && p.L <= kF9M && 2 * p.ybuf_len * 4 <= kF9Slots * 8 && N <= kF9NT * kR &&
+                          nn >= 1 && p.half + min_delay + nn <= p.L && nn <= kB2Seg && nn <= 256 &&
+                          ceil_div(kB2Seg + M - 1, kB2R) <= 256 && p.b2_exact_smem_bytes <= 64 * 1024;
+        p.band2 = fits ? 1 : 0;
+    }
     return off <= 160 * 1024;
 }
 
@@ -153,6 +175,29 @@ inline void build_coef_tables(HostTables& t, int nb, int K, int M, const double*
     for (int b = 0; b < nb; ++b) {
         for (int j = 0; j < K; ++j) t.taps_rev[(size_t)b * kn + j] = taps[(size_t)b * K + (K - 1 - j)];
         for (int j = 0; j < M; ++j) t.chirp[(size_t)b * mn + j] = chirps[(size_t)b * M + j];
+    }
+}
+
+// Error bounds of the pair kernel's float32 matched filter (u = 2^-24), per band:
+//   float32 FIR: |fl(band_sig[n]) - band_sig[n]| <= (K + 2) u ||taps||_1 max|y|  (y rounded to float32, K-term
+//   fused multiply-add sum), which moves a lag by at most ||chirp||_1 times that;
+//   float32 transforms: two 4608-point FFTs (passes of radix 9, 8, 8, 8) and the pointwise product move the
+//   convolution by at most c u ||x||_2 max|G| in the 2-norm, hence every lag by as much, with c = 200: Higham,
+//   Accuracy and Stability of Numerical Algorithms, Thm 24.2 gives log2(n) (mu + gamma_4 (sqrt 2 + mu)) ~ 82 u per
+//   transform for correctly rounded twiddles, 2 * 82 u + 4 u for the product, rounded up.
+inline void band2_bounds(BandParams& p, const double* taps, const double* chirps) {
+    const double u = 5.9604644775390625e-8;
+    for (int b = 0; b < p.nb && b < 3; ++b) {
+        double t1 = 0.0, c1 = 0.0;
+        for (int j = 0; j < p.K; ++j) t1 += std::fabs(taps[(size_t)b * p.K + j]);
+        for (int j = 0; j < p.M; ++j) c1 += std::fabs(chirps[(size_t)b * p.M + j]);
+        std::vector<std::complex<double>> g(kF9M, std::complex<double>(0, 0));
+        for (int j = 0; j < p.M; ++j) g[j] = chirps[(size_t)b * p.M + j];
+        fft_23(g);
+        double gmax = 0.0;
+        for (int k = 0; k < kF9M; ++k) gmax = std::max(gmax, std::abs(g[k]));
+        p.eps_fir[b] = (double)(p.K + 2) * u * t1 * c1;
+        p.eps_fft[b] = 200.0 * u * gmax;
     }
 }
 
@@ -225,6 +270,20 @@ inline void build_tables(HostTables& t, const BandParams& p, const double* taps,
         };
         r8(t.f9twa, 64);
         r8(t.f9twb, 8);
+    }
+    if (p.band2) {
+        // matched filter as a cyclic convolution of length 4608 with g[t] = chirp[M-1-t]:
+        // (band_sig * g)[k] = sum_j chirp[j] band_sig[k - (M-1) + j] = scipy.signal.correlate(band_sig, chirp, 'full')[k]
+        t.f9ghat.resize((size_t)p.nb * kF9M);
+        for (int b = 0; b < p.nb; ++b) {
+            std::vector<std::complex<double>> g(kF9M, std::complex<double>(0, 0));
+            for (int j = 0; j < p.M; ++j) g[p.M - 1 - j] = chirps[(size_t)b * p.M + j];
+            fft_23(g);
+            for (int pos = 0; pos < kF9M; ++pos) {
+                const std::complex<double> v = g[pass_order_freq9(pos)] / (double)kF9M;
+                t.f9ghat[(size_t)b * kF9M + pos] = mk(v.real(), v.imag());
+            }
+        }
     }
     t.post.resize((size_t)2 * (n2 + 1));
     for (int k = 0; k <= n2; ++k) {
