@@ -824,7 +824,7 @@ int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_windo
 // grown on demand.  With ext nothing is allocated, no prefetched IIR is consumed and no timing events are recorded.
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
-                      double* quality, const Scratch* ext = nullptr) {
+                      double* quality, const Scratch* ext = nullptr, double* corr_out = nullptr) {
     if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
@@ -906,7 +906,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 0;
-            p.d_in = y_in; p.res_out = sc.res; p.corr_io = h->d_corr; p.bandf_out = sc.bandf;
+            double* corr = corr_out ? corr_out + (size_t)f0 * nb * p.L : h->d_corr;     // raw correlation: the caller's, or scratch
+            p.d_in = y_in; p.res_out = sc.res; p.corr_io = corr; p.bandf_out = sc.bandf;
             rc = launch_band(p, n, s);
             if (rc) return rc;
         } else {
@@ -937,7 +938,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_spec_hilbert(q, n, s);
             if (rc) return rc;
             EnvParams e = h->ebase;
-            e.corr = h->d_corr; e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
+            e.corr = corr_out ? corr_out + (size_t)f0 * nb * e.L : h->d_corr;
+            e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
             rc = launch_corr_env(e, n, s);
             if (rc) return rc;
         } else if (spec_db) {
@@ -977,6 +979,12 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, 
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality, double* kalman_x,
                     double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
     return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
+}
+
+int echo_chain_wave(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* corr, double* quality,
+                    double* kalman_x, double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
+    if (!spec_db || !corr) return ECHO_ERR_INVALID;
+    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality, nullptr, corr);
 }
 
 int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,

@@ -296,6 +296,25 @@ class EchoEngine:
             raise _lib.EchoError(f"unknown chain mode {mode!r}")
         return out, spec
 
+    def chain_wave(self, rx, n_streams: Optional[int] = None, kalman: Optional["BatchedKalman"] = None):
+        """One pass of SonarWorker.run()'s loop body with everything it hands on (airSonar_optimized.py:703-757): the
+        full chain's records plus, for every frame, the dB spectra and the raw correlations of the waveSig payload.
+        Returns (records uint8 [B,64], spec_db f32 [B,nb,bins], corr f64 [B,nb,L])."""
+        rx = self._in(rx, torch.float32, (-1, self.cfg.n_rx), "rx")
+        B, nb = rx.shape[0], self.cfg.n_bands
+        out = self._empty((B, 64), torch.uint8)
+        spec = self._empty((B, nb, self.cfg.n_bins), torch.float32)
+        corr = self._empty((B, nb, self.cfg.n_corr), torch.float64)
+        S = n_streams if n_streams is not None else (kalman.S if kalman is not None else max(B, 1))
+        kx = kp = ki = None
+        if kalman is not None:
+            if kalman.S != S or kalman.engine.device != self.device:
+                raise _lib.EchoError("kalman state must hold n_streams streams on the engine's device")
+            kx, kp, ki = kalman.x, kalman.p, kalman.init
+        self._call("echo_chain_wave", self._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(corr), None, _ptr(kx), _ptr(kp),
+                   _ptr(ki), B, S, self._stream())
+        return out, spec, corr
+
     def chain_noalloc(self, rx: torch.Tensor, out: torch.Tensor, spec_out: Optional[torch.Tensor] = None,
                       n_streams: Optional[int] = None, kalman: Optional["BatchedKalman"] = None):
         """``chain`` (named mode) through the entry point that allocates nothing: every buffer is the caller's

@@ -40,6 +40,20 @@ def csv_rows(rows: np.ndarray, timestamps: Optional[Sequence[float]] = None, n_b
     return out
 
 
+def csv_text(rows: np.ndarray, timestamps: Optional[Sequence[float]] = None, n_bands: int = 3, header: bool = True) -> str:
+    """distances.csv as the reference writes it: the header row of SonarWorker.__init__ (:614-616) and one
+    ``csv.writer`` row per frame with a valid band (:746-747)."""
+    import csv
+    import io
+    buf = io.StringIO(newline="")
+    w = csv.writer(buf)
+    if header:
+        w.writerow(["timestamp", "distance", "confidence", "band_snrs"])
+    for row in csv_rows(rows, timestamps, n_bands):
+        w.writerow(row)
+    return buf.getvalue()
+
+
 def log_lines(rows: np.ndarray, n_bands: int = 3) -> List[Optional[str]]:
     """The INFO line of :741-743 per frame (None when no band produced a range)."""
     out = []
@@ -50,6 +64,12 @@ def log_lines(rows: np.ndarray, n_bands: int = 3) -> List[Optional[str]]:
         dist_kf, snrs, avg = sig
         out.append(f"distance = {dist_kf:.2f} m  (band SNRs: {['%.1f' % s for s in snrs]}, confidence: {avg:.1f}%)")
     return out
+
+
+def wave_sigs(rx: np.ndarray, spec_db: np.ndarray, corr: np.ndarray, first_id: int = 1) -> List[dict]:
+    """The waveSig payloads of a batch (:749-757) from ``EchoEngine.chain_wave``'s arrays: rx [B,N], spec_db
+    [B,nb,bins], corr [B,nb,L]; ``rx_id`` counts frames from ``first_id`` (update_counter, :748, :755)."""
+    return [wave_sig(rx[i], list(spec_db[i]), list(corr[i]), first_id + i) for i in range(len(rx))]
 
 
 def wave_sig(rx: np.ndarray, band_spectra: Iterable[np.ndarray], correlations: Optional[Iterable[np.ndarray]],

@@ -212,6 +212,14 @@ int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
 
+/* One pass of SonarWorker.run()'s loop body with everything it hands on (airSonar_optimized.py:703-757): the records
+ * of echo_chain_full (what the log line :741-743, distanceSig :745 and the CSV row :746-747 are made of) plus the
+ * waveSig arrays of every frame: spec_db[B][nb][N/2+1] ('band_spectra', :710, :752) and corr[B][nb][N+M-1], the raw
+ * correlations ('correlations', :712, :753; float64, unmodified: the envelope path of _process_band_gpu does not write
+ * into its corr, and process_band_with_output keeps its own).  Both are required; other arguments as echo_chain_full. */
+int echo_chain_wave(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* corr, double* quality,
+                    double* kalman_x, double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream);
+
 /* echo_chain without any allocation (no counterpart in the reference).  For callers that cannot call hipMalloc: code
  * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments and results as
  * echo_chain; the scratch of the pass (IIR forward output, IIR result, float32 band signal, detector records, fused

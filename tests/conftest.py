@@ -61,6 +61,16 @@ def gold_realtime():
     return load_golden("realtime")
 
 
+@pytest.fixture(scope="session")
+def gold_loop_default():
+    return load_golden("run_loop_default")
+
+
+@pytest.fixture(scope="session")
+def gold_loop_distinct():
+    return load_golden("run_loop_distinct")
+
+
 def rx_from_i16(q):
     """AudioIO.record quantisation (airSonar_optimized.py:573)."""
     return q.astype(np.float32) / 2 ** 15

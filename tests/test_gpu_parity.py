@@ -120,19 +120,27 @@ def test_fir_bank_is_convolve_same(gold_default, eng_default):
             assert np.abs(out[i, j] - ref).max() <= 1e-14
 
 
-def test_chain_4096_frames_bit_exact_peaks_vs_oracle(eng_default):
-    """BASELINE.json configs[1]: 4096 synthetic frames on one GPU, full chain, peak indices bit-exact vs NumPy/SciPy."""
-    cfg = eng_default.cfg
-    t = eng_default.tables
-    B = 4096
-    rx = synth_frames(B, cfg, t.tx_pcm)
+@pytest.mark.parametrize("which,mode,B", [("default", "named", 4096), ("distinct", "named", 4096),
+                                          ("default", "full", 2048), ("distinct", "full", 2048)])
+def test_chain_4096_frames_bit_exact_peaks_vs_oracle(which, mode, B, eng_default, eng_distinct):
+    """BASELINE.json configs[1]: 4096 synthetic frames on one GPU, whole chain, peak indices bit-exact vs NumPy/SciPy;
+    both band sets (three copies of one band / three distinct bands); the full chain (envelope branch) on 2048."""
+    e = eng_default if which == "default" else eng_distinct
+    cfg = e.cfg
+    t = e.tables
+    rx = synth_frames(B, cfg, t.tx_pcm, start=0 if which == "default" else 50000)
     from dsp_amd.engine import BatchedKalman
     S = 64
-    kal = BatchedKalman(eng_default, S)
-    rec, spec = eng_default.chain(rx, n_streams=S, kalman=kal)
+    kal = BatchedKalman(e, S)
+    rec, spec = e.chain(rx, n_streams=S, kalman=kal, mode=mode)
     rec = _rec(rec)
-    exp = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=S, mode="named", keep=("spec_db",))
-    check_records(rec, exp)
+    exp = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=S, mode=mode, keep=("spec_db",))
+    if mode == "named":
+        check_records(rec, exp)
+    else:
+        assert np.array_equal(rec["peak_idx"][:, :3], exp["peak_idx"])
+        check_full_records(rec, {k: exp[k] for k in ("valid", "distance", "snr_db", "confidence", "valid_any",
+                                                      "fused_dist", "avg_conf", "kalman")}, cfg)
     check_spectra(spec.cpu().numpy()[::37], exp["spec_db"][::37])
     assert exp["valid"].sum() > 0.9 * exp["valid"].size
 

@@ -306,8 +306,159 @@ def run_twopeak(n_random=6):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "valid", int(valid.sum()), "of", valid.size)
 
 
+def adversarial_frames(cfg, tx_mix, rng):
+    """Frames built to stress the argmax: echoes of (nearly) equal strength, echoes a few samples apart, a noise-free
+    periodic input whose correlation repeats, a tone at the band centre (flat correlation envelope), a loud frame
+    next to silence, an echo straddling the blind-zone edge, impulses."""
+    n, m = cfg.n_rx, len(tx_mix)
+    base = cfg.half - (m - 1) + cfg.min_delay
+    frames, names = [], []
+
+    def put(name, x):
+        frames.append(quantise(x)); names.append(name)
+
+    def echo(x, lag, a):
+        k = max(0, min(m, n - lag))
+        x[lag:lag + k] += a * tx_mix[:k]
+
+    x = np.zeros(n); echo(x, base + 300, 0.25); echo(x, base + 1100, 0.25)
+    put("two_identical_echoes_no_noise", x)
+    x = np.zeros(n)
+    for q in range(5):
+        echo(x, base + 200 + 320 * q, 0.2)
+    put("five_identical_echoes_no_noise", x)
+    x = rng.normal(0, 0.0005, n); echo(x, base + 300, 0.25); echo(x, base + 1100, 0.2501)
+    put("two_echoes_1e-4_apart", x)
+    x = rng.normal(0, 0.002, n); echo(x, base + 500, 0.2); echo(x, base + 503, 0.2)
+    put("two_echoes_three_samples_apart", x)
+    t = np.arange(n)
+    put("tone_band0_centre", 0.3 * np.sin(2 * np.pi * (cfg.BANDS[0][0] + cfg.BANDS[0][1]) / 2 / cfg.FS * t))
+    put("tone_band2_centre", 0.3 * np.sin(2 * np.pi * (cfg.BANDS[2][0] + cfg.BANDS[2][1]) / 2 / cfg.FS * t))
+    x = rng.normal(0, 0.3, n); echo(x, base + 900, 0.9)
+    put("loud", x)
+    put("silence_after_loud", np.zeros(n))
+    put("faint_noise", rng.normal(0, 0.0002, n))
+    x = rng.normal(0, 0.002, n); echo(x, cfg.half - (m - 1) + cfg.min_delay - 1, 0.3)
+    put("echo_peak_last_blind_sample", x)
+    x = rng.normal(0, 0.002, n); echo(x, cfg.half - (m - 1) + cfg.min_delay, 0.3)
+    put("echo_peak_first_open_sample", x)
+    x = np.zeros(n); x[base + 400] = 0.9; x[base + 1500] = -0.9
+    put("impulses", x)
+    x = rng.normal(0, 0.004, n); echo(x, n - m - 2, 0.3)
+    put("echo_at_frame_end", x)
+    x = np.zeros(n); echo(x, 900, 0.3)
+    put("echo_only_in_first_half", x)
+    x = np.full(n, 0.5)
+    put("dc", x)
+    return np.stack(frames), names
+
+
+def run_loop_capture(tag="default", bands=C.BANDS_DEFAULT):
+    """SonarWorker.run() of airSonar_optimized.py itself (:678-768) on the golden frames followed by adversarial ones,
+    with the sound card replaced by the frames and the sinks captured: the INFO lines (:741-743), the distanceSig
+    arguments (:745), the CSV file (:746-747) and the waveSig payload of the first frames (:749-757).  This pins the
+    result / wire formats and the whole loop body (envelope branch, fusion, Kalman) on the reference's own code."""
+    import csv
+    import logging
+    import types
+    import airSonar_optimized as ref
+    ref.cfg = ref.Config(BANDS=tuple(bands))
+    cfg = C.optimized_config(bands)
+    gold = np.load(os.path.join(GOLD, f"optimized_{tag}.npz"))
+    tx_mix = gold["tx_pcm"].astype(np.float64) / 32768.0
+    adv, adv_names = adversarial_frames(cfg, tx_mix, np.random.default_rng(4242))
+    rx_i16 = np.concatenate([gold["rx_i16"], adv])
+    frames = [q.astype(np.float32) / 2 ** 15 for q in rx_i16]
+
+    class FakeAudio:
+        def __init__(self):
+            self.i = 0
+        def play(self, pcm):
+            pass
+        def record(self):
+            x = frames[self.i]; self.i += 1
+            if self.i >= len(frames):
+                worker.stop_event.set()
+            return x
+        def close(self):
+            pass
+
+    class Capture:
+        def __init__(self):
+            self.calls = []
+        def emit(self, *a):
+            self.calls.append(a)
+
+    lines = []
+    class Handler(logging.Handler):
+        def emit(self, record):
+            lines.append(record.getMessage())
+    h = Handler(); ref.logger.addHandler(h)
+    if os.path.exists("distances.csv"):
+        os.remove("distances.csv")
+    real_time = ref.time
+    ref.time = types.SimpleNamespace(perf_counter=real_time.perf_counter, sleep=lambda s: None, time=lambda: 1234.5)
+    ref.AudioIO = FakeAudio
+    worker = ref.SonarWorker()
+    worker.distanceSig = Capture(); worker.waveSig = Capture(); worker.errorSig = Capture()
+    try:
+        worker.run()
+    finally:
+        ref.time = real_time
+        ref.logger.removeHandler(h)
+    assert not worker.errorSig.calls, worker.errorSig.calls
+    waves = worker.waveSig.calls
+    assert len(waves) == len(frames)
+    with open("distances.csv", newline="") as f:
+        csv_text = f.read()
+    log = [l for l in lines if l.startswith("distance = ")]
+    dsig = worker.distanceSig.calls
+    assert len(log) == len(dsig)
+    # which frames produced a result: recovered from the waveSig ids and the order of the emissions
+    nb = len(bands)
+    B = len(frames)
+    keep = 3                                                   # waveSig arrays of the first frames only (size)
+    out = dict(
+        rx_i16=rx_i16, n_golden=len(gold["rx_i16"]), adversarial_names=np.array(adv_names), bands=np.array(bands),
+        log_lines=np.array(log), csv_text=np.array(csv_text),
+        dsig_dist=np.array([d[0] for d in dsig]), dsig_avg_conf=np.array([d[2] for d in dsig]),
+        dsig_nsnr=np.array([len(d[1]) for d in dsig]), dsig_snrs=np.array([s for d in dsig for s in d[1]]),
+        wave_keys=np.array(sorted(waves[0][0].keys())),
+        wave_rx_id=np.array([w[0]["rx_id"] for w in waves]),
+        wave_band_lengths=np.array([w[0]["band_lengths"] for w in waves]),
+        wave_spectra=np.stack([np.stack(w[0]["band_spectra"]) for w in waves[:keep]]).astype(np.float32),
+        wave_correlations=np.stack([np.stack(w[0]["correlations"]) for w in waves[:keep]]),
+        numpy_version=np.__version__, scipy_version=scipy.__version__)
+    # per frame and band, the reference's own functions once more for the scalars the parity tests compare
+    filters = worker.filters; chirps = worker.chirps
+    me = _Self()
+    peak = np.full((B, nb), -1, np.int32); snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); valid = np.zeros((B, nb), bool)
+    fd = np.zeros((B, nb)); fc = np.zeros((B, nb)); fs = np.zeros((B, nb)); fv = np.zeros((B, nb), bool)
+    for i in range(B):
+        for j in range(nb):
+            band_sig = ref.bandpass(frames[i], filters[j])
+            corr = ref.gpu_correlate(band_sig, chirps[j])
+            p, s = ref.first_strong_peak(corr, ref.cfg.FS, cfg.min_delay)
+            amp[i, j] = float(np.max(np.abs(corr)))
+            if p is not None:
+                peak[i, j] = p; snr[i, j] = s; valid[i, j] = True
+            d, c, s2 = ref.SonarWorker._process_band_gpu(me, frames[i], chirps[j], filters[j], j)
+            if d is not None:
+                fd[i, j] = d; fc[i, j] = c; fs[i, j] = s2; fv[i, j] = True
+    out.update(peak_idx=peak, snr_db=snr, amplitude=amp, valid=valid,
+               full_distance=fd, full_confidence=fc, full_snr=fs, full_valid=fv)
+    path = os.path.join(GOLD, f"run_loop_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "frames", B, "results", len(dsig),
+          "named valid", int(valid.sum()), "full valid", int(fv.sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "run_loop":     # only the captured run() loops (needs the optimized goldens)
+        run_loop_capture("default", C.BANDS_DEFAULT)
+        run_loop_capture("distinct", C.BANDS_DISTINCT)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "twopeak":      # only the 666.py variant
         run_twopeak()
         sys.exit(0)
@@ -316,3 +467,5 @@ if __name__ == "__main__":
     run_original()
     run_realtime()
     run_twopeak()
+    run_loop_capture("default", C.BANDS_DEFAULT)
+    run_loop_capture("distinct", C.BANDS_DISTINCT)
