@@ -13,6 +13,7 @@
 
 using namespace echo;
 
+constexpr int kEvPerSlot = 6;               // timing events per profiled chain call
 constexpr int kInnerChunk = 8192;          // frames per pass when a many-pass call pipelines its own IIRs
 
 // Device scratch of one internal pass of the chain: everything beyond the caller's inputs and outputs.
@@ -89,8 +90,9 @@ struct EchoHandle {
     int iir_lps = 0;                       // lanes per sequence in the quad kernel: 0 = choose, 4 or 16 (ECHO_IIR_LPS)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
-    std::vector<hipEvent_t> ev;            // 5 events per slot: start, after IIR, after band, after spectrum, end
+    std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
     int prof_slots = 0, prof_used = 0;
+    std::vector<char> prof_pair;           // per slot: the band stage ran as pair kernel + exact kernel (event 5 recorded)
     bool capturing = false;                // inside echo_graph_create's stream capture
     int live_graphs = 0;                   // recorded graphs hold pointers into the scratch: it must not move while > 0
 };
@@ -491,7 +493,7 @@ int echo_set_profiling(EchoHandle* h, int slots) {
     if (!h || slots < 0) return ECHO_ERR_INVALID;
     h->prof = slots > 0;
     h->prof_used = 0;
-    while ((int)h->ev.size() < 5 * slots) {
+    while ((int)h->ev.size() < kEvPerSlot * slots) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
         h->ev.push_back(e);
@@ -504,7 +506,7 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
     if (!h || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
     double acc[4] = {0, 0, 0, 0};
     for (int k = 0; k < h->prof_used; ++k) {
-        hipEvent_t* e = &h->ev[5 * k];
+        hipEvent_t* e = &h->ev[kEvPerSlot * k];
         if (hipEventSynchronize(e[4]) != hipSuccess) return ECHO_ERR_HIP;
         for (int j = 0; j < 4; ++j) {
             float x = 0;
@@ -517,6 +519,32 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
     if (band_ms) *band_ms = (float)(acc[1] / n);
     if (spec_ms) *spec_ms = (float)(acc[2] / n);
     if (fuse_ms) *fuse_ms = (float)(acc[3] / n);
+    h->prof_used = 0;
+    return ECHO_OK;
+}
+
+int echo_kernel_times(EchoHandle* h, float* ms, int n) {
+    if (!h || !ms || n < 1 || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
+    double acc[6] = {0, 0, 0, 0, 0, 0};              // iir, band stage, spectrum, fusion, pair kernel, exact kernel
+    int npair = 0;
+    for (int k = 0; k < h->prof_used; ++k) {
+        hipEvent_t* e = &h->ev[kEvPerSlot * k];
+        if (hipEventSynchronize(e[4]) != hipSuccess) return ECHO_ERR_HIP;
+        for (int j = 0; j < 4; ++j) {
+            float x = 0;
+            if (hipEventElapsedTime(&x, e[j], e[j + 1]) != hipSuccess) return ECHO_ERR_HIP;
+            acc[j] += x;
+        }
+        if (k < (int)h->prof_pair.size() && h->prof_pair[k]) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, e[1], e[5]) != hipSuccess || hipEventElapsedTime(&b, e[5], e[2]) != hipSuccess)
+                return ECHO_ERR_HIP;
+            acc[4] += a; acc[5] += b; ++npair;
+        }
+    }
+    const double cnt = (double)h->prof_used;
+    for (int j = 0; j < n && j < 6; ++j) ms[j] = (float)(j < 4 ? acc[j] / cnt : (npair ? acc[j] / npair : 0.0));
+    for (int j = 6; j < n; ++j) ms[j] = 0.f;
     h->prof_used = 0;
     return ECHO_OK;
 }
@@ -863,7 +891,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         if (full) { rc = ensure_full_scratch(h, n); if (rc) return rc; }
         const Scratch& sc = ext ? *ext : h->sc;
         const bool prof = !ext && h->prof && f0 == 0 && h->prof_used < h->prof_slots;
-        hipEvent_t* ev = prof ? &h->ev[5 * h->prof_used] : nullptr;
+        hipEvent_t* ev = prof ? &h->ev[kEvPerSlot * h->prof_used] : nullptr;
+        bool pair_timed = false;
         if (prof) (void)hipEventRecord(ev[0], s);
         // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
         const bool pre = inner || (!ext && f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B);
@@ -920,6 +949,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             else {
                 rc = launch_band2_pair(p, n, s);
                 if (rc) return rc;
+                if (prof) { (void)hipEventRecord(ev[5], s); pair_timed = true; }
                 rc = launch_band2_exact(p, n, s);
             }
             if (rc) return rc;
@@ -961,7 +991,12 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_kalman(k, s);
             if (rc) return rc;
         }
-        if (prof) { (void)hipEventRecord(ev[4], s); ++h->prof_used; }
+        if (prof) {
+            (void)hipEventRecord(ev[4], s);
+            if ((int)h->prof_pair.size() <= h->prof_used) h->prof_pair.resize(h->prof_used + 1);
+            h->prof_pair[h->prof_used] = pair_timed;
+            ++h->prof_used;
+        }
     }
     if (h->pf_stream && h->pf_gate && !h->capturing) {
         h->chain_gen ^= 1;

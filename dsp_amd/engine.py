@@ -390,9 +390,11 @@ class EchoEngine:
         self._call("echo_set_profiling", self._h, int(slots))
 
     def last_kernel_ms(self):
-        a, b, c, d = C.c_float(), C.c_float(), C.c_float(), C.c_float()
-        self._call("echo_last_kernel_ms", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        return {"iir": a.value, "band": b.value, "spec": c.value, "fuse": d.value}
+        """Average device time (HIP events on the call's stream) of the stages of the armed chain calls: 'band' is the
+        whole band stage; 'pair' and 'exact' its two kernels where it runs as two (0 otherwise)."""
+        ms = (C.c_float * 6)()
+        self._call("echo_kernel_times", self._h, ms, 6)
+        return dict(zip(("iir", "band", "spec", "fuse", "pair", "exact"), (float(x) for x in ms)))
 
 
 class ChainGraph:

@@ -277,6 +277,10 @@ void echo_graph_destroy(EchoGraph* graph);
  * (first internal pass of each call), then re-arms from slot 0.  No counterpart in the reference. */
 int echo_set_profiling(EchoHandle* h, int slots);
 int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spec_ms, float* fuse_ms);
+/* The same averages as an array, with the band stage split where it runs as two kernels: ms[0..5] = IIR, band stage,
+ * spectrum, fusion(+Kalman), pair kernel (float32 matched filter), exact kernel (float64 re-evaluation); the last two
+ * are 0 when the band stage is the single-frame kernel.  Entries beyond 5 are set to 0. */
+int echo_kernel_times(EchoHandle* h, float* ms, int n);
 
 #ifdef __cplusplus
 }

@@ -1,32 +1,99 @@
 #!/usr/bin/env python3
-"""One-off larger parity run: the GPU chain against the oracle on many synthetic frames (named and full mode, both
-band sets).  Prints mismatch counts; exits non-zero on any index mismatch.  Usage: bulk_parity.py [frames]"""
-import os, sys, time
-import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dsp_amd import config as C
-from dsp_amd.engine import EchoEngine, BatchedKalman, records_to_numpy
-from dsp_amd.synth import synth_frames
-from oracle import echo_oracle as O
+"""Larger parity run: the GPU chain against the oracle on many synthetic frames (named and full chain, both band
+sets).  The oracle runs in worker processes on frame shards (they never touch the GPU); the parent runs the GPU chain,
+replays the Kalman filter over the oracle's fused ranges and writes a JSON summary.
+Usage: bulk_parity.py [frames] [workers] [out.json]; exits non-zero on any index or validity mismatch."""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-bad = 0
-for bands in (C.BANDS_DEFAULT, C.BANDS_DISTINCT):
-    cfg = C.optimized_config(bands)
-    eng = EchoEngine(cfg)
-    rx = synth_frames(n, cfg, eng.tables.tx_pcm, start=100000)
-    for mode in ("named", "full"):
-        t0 = time.time()
-        o = O.chain(rx, eng.tables.chirps_f32, eng.tables.filters, cfg, n_streams=64, mode=mode)
-        rec, _ = eng.chain(rx, n_streams=64, kalman=BatchedKalman(eng, 64), mode=mode, want_spectra=False)
-        r = records_to_numpy(rec)
-        mism = int((r["peak_idx"][:, :3] != o["peak_idx"]).sum())
-        v = o["valid"]
-        dconf = np.abs(r["conf"][:, :3][v] - o["confidence"][v]) / np.maximum(np.abs(o["confidence"][v]), 1e-12)
-        dsnr = np.abs(r["snr_db"][:, :3][v] - o["snr_db"][v]) / np.maximum(np.abs(o["snr_db"][v]), 1e-12)
-        dk = np.abs(r["kalman"] - o["kalman"]).max()
-        print(f"bands={bands[0]}.. mode={mode}: {n} frames, index mismatches {mism}, max rel conf err {dconf.max():.2e}, "
-              f"max rel snr err {dsnr.max():.2e}, max kalman abs err {dk:.2e}  ({time.time() - t0:.0f} s)", flush=True)
-        bad += mism
-    eng.close()
-sys.exit(1 if bad else 0)
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+START = 100000
+CHUNK = 500
+
+
+def _oracle_shard(job):
+    which, mode, lo, n = job
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    from dsp_amd import config as C
+    from dsp_amd.design import build_tables
+    from dsp_amd.synth import synth_frames
+    from oracle import echo_oracle as O
+    cfg = C.optimized_config(C.BANDS_DEFAULT if which == "default" else C.BANDS_DISTINCT)
+    t = build_tables(cfg)
+    rx = synth_frames(n, cfg, t.tx_pcm, start=START + lo)
+    o = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=n, mode=mode)
+    return lo, {k: o[k] for k in ("peak_idx", "valid", "snr_db", "confidence", "distance", "fused_dist", "avg_conf", "valid_any")}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 else min(16, os.cpu_count() or 1)
+    out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    from dsp_amd import config as C
+    from dsp_amd.engine import BatchedKalman, EchoEngine, records_to_numpy
+    from dsp_amd.synth import synth_frames
+    from oracle import echo_oracle as O
+    S = 64
+    n -= n % S
+    summary = {"frames_per_leg": n, "first_frame_seed_index": START, "n_streams": S, "oracle_workers": workers, "legs": []}
+    bad = 0
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        for which in ("default", "distinct"):
+            cfg = C.optimized_config(C.BANDS_DEFAULT if which == "default" else C.BANDS_DISTINCT)
+            eng = EchoEngine(cfg)
+            rx = synth_frames(n, cfg, eng.tables.tx_pcm, start=START)
+            for mode in ("named", "full"):
+                t0 = time.time()
+                jobs = [(which, mode, lo, min(CHUNK, n - lo)) for lo in range(0, n, CHUNK)]
+                o = {}
+                done = 0
+                for lo, part in pool.imap_unordered(_oracle_shard, jobs):
+                    for k, a in part.items():
+                        o.setdefault(k, np.zeros((n,) + a.shape[1:], a.dtype))[lo:lo + len(a)] = a
+                    done += 1
+                    if done % 20 == 0:
+                        print(f"  {which}/{mode}: oracle {done * CHUNK}/{n} frames, {time.time() - t0:.0f} s", flush=True)
+                kfs = [O.ScalarKalman(cfg.KALMAN_Q, cfg.KALMAN_R) for _ in range(S)]
+                kal = np.zeros(n)
+                for i in range(n):
+                    kf = kfs[i % S]
+                    kal[i] = kf.update(o["fused_dist"][i]) if o["valid_any"][i] else (kf.x if kf.x is not None else 0.0)
+                rec, _ = eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), mode=mode, want_spectra=False)
+                r = records_to_numpy(rec)
+                valid = ((r["valid_mask"][:, None] >> np.arange(3)) & 1).astype(bool)
+                v = o["valid"]
+                if mode == "full":      # the oracle's full-chain index: recovered from the distance (an index into corr)
+                    want_idx = np.rint(o["distance"] * 2 * cfg.FS / cfg.sound_speed).astype(np.int64) + cfg.range_offset
+                    mism = int((r["peak_idx"][:, :3][v] != want_idx[v]).sum())
+                else:
+                    mism = int((r["peak_idx"][:, :3] != o["peak_idx"]).sum())
+                vmism = int((valid != v).sum())
+                rel = lambda a, b: float((np.abs(a - b) / np.maximum(np.abs(b), 1e-12)).max()) if len(b) else 0.0
+                leg = {"bands": which, "mode": mode, "frames": n, "frame_bands": int(n * 3), "valid_frame_bands": int(v.sum()),
+                       "index_mismatches": mism, "validity_mismatches": vmism,
+                       "max_rel_err_snr": rel(r["snr_db"][:, :3][v], o["snr_db"][v]),
+                       "max_rel_err_confidence": rel(r["conf"][:, :3][v], o["confidence"][v]),
+                       "max_rel_err_distance": rel(r["dist"][:, :3][v], o["distance"][v]),
+                       "max_rel_err_fused": rel(r["fused_dist"][o["valid_any"]], o["fused_dist"][o["valid_any"]]),
+                       "max_abs_err_kalman": float(np.abs(r["kalman"] - kal).max()), "oracle_seconds": round(time.time() - t0, 1)}
+                print(json.dumps(leg), flush=True)
+                summary["legs"].append(leg)
+                bad += mism + vmism
+            eng.close()
+    summary["total_index_or_validity_mismatches"] = bad
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(summary, f, indent=1)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
