@@ -8,6 +8,9 @@ correlation, first_strong_peak, confidence fusion, Kalman) over one batch of 409
 inputs resident in HBM before the timed region.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) every rank processes its own 4096-frame shard of the global batch and the 64-byte
 result records are all-gathered over RCCL each step -- the only exchange on this path.
+With --total-frames T the job is the sharded configuration instead (strong scaling): T distinct frames, generated on
+the devices, are split into contiguous shards over the ranks, a step is one pass over all T frames plus one gather of
+the records.
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -32,17 +35,23 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (one-core leg)")
-    ap.add_argument("--cpu-workers", type=int, default=16, help="processes of the all-cores CPU-baseline leg")
-    ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("START", "COUNT"),
-                    help="internal: run the CPU oracle on one frame shard and print the seconds taken")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong-scaling job: this many distinct device-synthesised frames split over the ranks "
+                         "(BASELINE configs[2] is 1000000); a step is one pass over all of them")
+    ap.add_argument("--cpu-frames", type=int, default=2048, help="CPU baseline: frames per timed run")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="CPU baseline: timed runs of the one-core leg (median)")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="processes of the all-cores CPU-baseline leg (0: this process's CPU share -- "
+                         "OMP_NUM_THREADS when set, else the CPUs it may run on)")
+    ap.add_argument("--cpu-worker", nargs=4, type=int, metavar=("START", "COUNT", "RUNS", "PIN"),
+                    help="internal: time the CPU oracle RUNS times on one frame shard, pinned to core PIN (-1: not "
+                         "pinned); prints the seconds of every run")
     ap.add_argument("--no-spectra", action="store_true", help="results only (17,188 B/frame variant)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (exercises the "
                          "multi-GPU code path on a one-GPU box)")
     ap.add_argument("--device-synth", action="store_true",
-                    help="generate the batch in device memory (every frame distinct, no upload); the CPU baseline "
-                         "then runs on frames downloaded from the device")
+                    help="generate the batch in device memory (every frame distinct, no upload)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not start the next step's IIR on the engine's own stream during the current step")
     ap.add_argument("--mode", choices=("named", "full"), default="named",
@@ -54,11 +63,16 @@ def parse():
     return ap.parse_args()
 
 
-def _cpu_worker(job):
-    """One host process of the all-cores baseline: rebuilds the tables and runs the oracle on its own frame shard."""
-    start, count, n_streams = job
+def _cpu_worker(start, count, runs, pin):
+    """One host process of the CPU baseline: rebuilds the tables, synthesises its own frame shard and times the oracle
+    chain `runs` times over it, single-threaded, pinned to one core when asked."""
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[k] = "1"
+    if pin >= 0:
+        try:
+            os.sched_setaffinity(0, {pin})
+        except OSError:
+            pass
     from dsp_amd.config import optimized_config
     from dsp_amd.design import build_tables
     from dsp_amd.synth import synth_frames
@@ -66,53 +80,78 @@ def _cpu_worker(job):
     cfg = optimized_config()
     tables = build_tables(cfg)
     rx = synth_frames(count, cfg, tables.tx_pcm, start=start)
-    t0 = time.perf_counter()
-    O.chain(rx, tables.chirps_f32, tables.filters, cfg, n_streams=n_streams, mode="named", keep=("spec_db",))
-    return time.perf_counter() - t0
-
-
-def cpu_baseline(cfg, tables, rx_host, budget_s, workers):
-    """The oracle (NumPy/SciPy restatement of the reference chain) on the host: one core on a bounded sample of
-    the GPU batch, then the same chain on `workers` processes, each with its own shard of frames."""
-    from oracle import echo_oracle as O
-    t0 = time.perf_counter()
-    O.chain(rx_host[:32], tables.chirps_f32, tables.filters, cfg, n_streams=32, mode="named")
-    per = (time.perf_counter() - t0) / 32
-    n = int(max(64, budget_s / per))
-    n -= n % 64
-    t0 = time.perf_counter()
-    for f0 in range(0, n, len(rx_host)):                   # beyond one batch the sample goes round the batch again
-        m = min(len(rx_host), n - f0)
-        O.chain(rx_host[:m], tables.chirps_f32, tables.filters, cfg, n_streams=min(m, N_STREAMS), mode="named",
-                keep=("spec_db",))
-    dt = time.perf_counter() - t0
-    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{n} frames drawn from the {len(rx_host)} frames of the GPU batch, oracle/echo_oracle.py chain "
-                     f"(filtfilt, fftconvolve, rfft+mag2db, correlate, first_strong_peak, fusion, Kalman), "
-                     f"{dt:.1f} s on 1 thread"}
-    if workers > 1:
-        per_worker = max(64, int(n / 2) - int(n / 2) % 64)
+    ns = N_STREAMS if count % N_STREAMS == 0 else 1
+    O.chain(rx[:ns], tables.chirps_f32, tables.filters, cfg, n_streams=ns, mode="named", keep=("spec_db",))   # warm-up
+    out = []
+    for _ in range(runs):
         t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                                   str(w * per_worker), str(per_worker)], stdout=subprocess.PIPE, text=True)
-                 for w in range(workers)]
-        inner = []
-        for p in procs:
-            text, _ = p.communicate(timeout=600)
-            if p.returncode != 0:
-                raise RuntimeError("CPU-baseline worker failed")
-            inner.append(float(text.strip().splitlines()[-1]))
-        wall = max(inner)
-        out["all_cores"] = {"value": workers * per_worker / wall, "unit": "frames/s", "cores": workers,
-                            "sample": f"{workers} processes x {per_worker} frames, slowest process {wall:.1f} s "
-                                      f"(wall {time.perf_counter() - t0:.1f} s incl. interpreter start-up)"}
+        O.chain(rx, tables.chirps_f32, tables.filters, cfg, n_streams=ns, mode="named", keep=("spec_db",))
+        out.append(time.perf_counter() - t0)
     return out
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def cpu_baseline(frames, runs, workers):
+    """The oracle (NumPy/SciPy restatement of the reference chain) on the host, on the same synthetic frames as the GPU
+    batch (frame g is a function of g): (i) one process pinned to one core, single-threaded BLAS/FFT, median of `runs`
+    runs over `frames` frames; (ii) the same chain in `workers` processes, each with its own shard of frames and its own
+    core, median of three rounds of the slowest worker."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if workers <= 0:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+        workers = min(len(allowed), share) if share > 0 else len(allowed)
+
+    def spawn(start, count, nruns, pin):
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(start), str(count),
+                                 str(nruns), str(pin)], stdout=subprocess.PIPE, text=True)
+
+    def collect(p):
+        text, _ = p.communicate(timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError("CPU-baseline worker failed")
+        return [float(x) for x in text.strip().splitlines()[-1].split()]
+
+    one = collect(spawn(0, frames, runs, allowed[0]))
+    out = {"value": frames / _median(one), "unit": "frames/s", "cores": 1, "kind": "port",
+           "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "cpus_this_process_may_use": len(allowed),
+           "sample": f"frames 0..{frames - 1} of the GPU batch, oracle/echo_oracle.py chain (filtfilt, fftconvolve, "
+                     f"rfft+mag2db, correlate, first_strong_peak, fusion, Kalman), one process pinned to core "
+                     f"{allowed[0]}, 1 thread, median of {runs} runs ({', '.join(f'{t:.2f}' for t in one)} s)"}
+    if workers > 1:
+        rounds = 3
+        t0 = time.perf_counter()
+        procs = [spawn(w * frames, frames, rounds, allowed[w % len(allowed)]) for w in range(workers)]
+        times = [collect(p) for p in procs]
+        slowest = [max(t[r] for t in times) for r in range(rounds)]
+        out["all_cores"] = {"value": workers * frames / _median(slowest), "unit": "frames/s", "cores": workers,
+                            "sample": f"{workers} pinned processes x {frames} frames each, median of {rounds} rounds of "
+                                      f"the slowest process ({', '.join(f'{t:.2f}' for t in slowest)} s; wall "
+                                      f"{time.perf_counter() - t0:.1f} s incl. interpreter start-up)"}
+    return out
+
+
+def _largest_divisor(n, cap):
+    return max(d for d in range(1, cap + 1) if n % d == 0)
 
 
 def main():
     args = parse()
     if args.cpu_worker:
-        print(_cpu_worker((args.cpu_worker[0], args.cpu_worker[1], 64)))
+        print(" ".join(f"{t:.6f}" for t in _cpu_worker(*args.cpu_worker)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_dist
@@ -125,11 +164,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
     from dsp_amd.config import optimized_config, original_config, realtime_config, twopeak_config
+    from dsp_amd.dist import shard_bounds
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.synth import synth_frames
 
@@ -143,33 +182,45 @@ def main():
     cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config,
            "twopeak": twopeak_config}[args.workload]()
     eng = EchoEngine(cfg, dev)
-    B = args.frames
-    # batches beyond 4096 frames repeat a 4096-frame pool (the sharded 1M-frame configuration)
-    if args.device_synth:
-        rx = eng.synth_frames(B, first_frame=rank * B)
-        rx_host = rx[:min(B, 4096)].cpu().numpy()
+    strong = args.total_frames > 0
+    if strong:
+        # the sharded configuration: contiguous shards of one global batch of distinct frames (frame g depends on g only)
+        bounds = shard_bounds(args.total_frames, world)
+        counts = [hi - lo for lo, hi in bounds]
+        lo, hi = bounds[rank]
+        B, Bmax = hi - lo, max(counts)
+        rx = eng.synth_frames(B, first_frame=lo)
     else:
-        rx_host = synth_frames(min(B, 4096), cfg, eng.tables.tx_pcm, start=rank * min(B, 4096))
-        rx = torch.from_numpy(rx_host).to(dev)
-        if B > 4096:
-            rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
-    S = N_STREAMS if B % N_STREAMS == 0 else 1
+        B = Bmax = args.frames
+        counts = [B] * world
+        # batches beyond 4096 frames repeat a 4096-frame pool
+        if args.device_synth:
+            rx = eng.synth_frames(B, first_frame=rank * B)
+        else:
+            rx_host = synth_frames(min(B, 4096), cfg, eng.tables.tx_pcm, start=rank * min(B, 4096))
+            rx = torch.from_numpy(rx_host).to(dev)
+            if B > 4096:
+                rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
+    S = _largest_divisor(B, N_STREAMS)                      # 64 whenever the batch is a multiple of it
     kal = BatchedKalman(eng, S)
     eng.reserve(B)
     want_spec = not args.no_spectra
     # two record buffers: with several ranks the all-gather of step k is asynchronous and only has to be complete
-    # before step k+2 writes the same buffer again, so the collective never stalls the compute stream
-    recs = [torch.empty((B, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
-    rec = recs[0]
+    # before step k+2 writes the same buffer again, so the collective never stalls the compute stream.  Uneven shards
+    # are padded to the largest one inside the buffer the collective sends.
+    send = [torch.zeros((Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+    recs = [b[:B] for b in send]
     spec = torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
-    gathered = [torch.empty((world * B, 64), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    gathered = [torch.empty((world * Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
     works = [None, None]
     counter = [0]
 
     # Steady-state pipelining: the input of step k+1 is resident, so its zero-phase IIR (a sequential recurrence that
     # leaves the arithmetic units idle) is started on the engine's own stream as soon as step k has been issued.
     # Each step consumes one prefetched IIR and issues one, so K timed steps do the work of K full chains.
-    pipeline = not args.no_pipeline and B <= (16384 if args.workload in ("optimized", "realtime") else 4096)
+    # (A call of eight or more internal passes -- the sharded job -- pipelines its own passes the same way.)
+    pipeline = (not args.no_pipeline and not strong
+                and B <= (16384 if args.workload in ("optimized", "realtime") else 4096))
 
     def step():
         buf = counter[0] & 1
@@ -180,7 +231,7 @@ def main():
         if pipeline:
             eng.chain_prefetch(rx)
         if use_dist:
-            works[buf] = dist.all_gather_into_tensor(gathered[buf], recs[buf], async_op=True)
+            works[buf] = dist.all_gather_into_tensor(gathered[buf], send[buf], async_op=True)
 
     def fence():
         for w in works:
@@ -211,63 +262,89 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        frames = world * B * args.steps
+        frames = sum(counts) * args.steps
         bytes_per_frame = cfg.n_rx * 4 + 60 + (cfg.n_bands * cfg.n_bins * 4 if want_spec else 0)   # 42,892 for the headline
-        band_s = kms["band"] / 1e3
         # echo_chain runs batches beyond 16384 frames in passes of that size, and calls of 65536 frames or more in
-        # self-pipelined passes of 8192 (long-frame parameter sets: passes of 4096)
+        # self-pipelined passes of 8192 (long-frame parameter sets: passes of 4096); the event times are those of
+        # the first pass of each call
         if args.workload in ("original", "twopeak"):
             launch_frames = min(B, 4096)
         else:
             launch_frames = 8192 if B >= 65536 and os.environ.get("ECHO_INNER_PIPELINE", "1") != "0" else min(B, 16384)
-        achieved = bytes_per_frame * launch_frames / band_s / 1e9
+        # the dominant kernel: the longest of the chain's kernels by its event-measured duration in this run (the
+        # band stage is one kernel or, on the fast path of the named chain, the pair kernel + the exact kernel)
+        split = kms.get("pair", 0.0) > 0.0
+        cand = {"iir": kms["iir"], "spec": kms["spec"]}
+        if split:
+            cand.update({"pair": kms["pair"], "exact": kms["exact"]})
+        else:
+            cand["band"] = kms["band"]
+        dom = max(cand, key=cand.get)
+        names = {"iir": "iir_filtfilt kernel", "band": "band_kernel", "pair": "band2_kernel", "exact": "exact_kernel",
+                 "spec": "spectrum kernel"}
+        if args.workload in ("original", "twopeak"):
+            names.update({"band": "long-frame band stage (FIR + matched filter + detector kernels)"})
+        dom_s = cand[dom] / 1e3
+        achieved = bytes_per_frame * launch_frames / dom_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_band_kernel.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "traffic_kernels.json")
+        if os.path.exists(tpath) and args.workload == "optimized" and args.mode == "named" and launch_frames == FRAMES_PER_STEP:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") if args.workload == "optimized" and B == FRAMES_PER_STEP else None
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch", {}).get(dom)
             except Exception:
                 traffic = None
+        wl = (f"configs[2]: {args.total_frames} distinct synthetic rx frames (generated on the devices) sharded over "
+              f"{world} GPU(s), one pass per step, " if strong else
+              (f"configs[1]: " if args.workload == "optimized" else f"variant '{args.workload}': ")
+              + f"{B} synthetic rx frames per GPU per step, ")
         out = {
             "metric": "echo frames/sec (3-band filter+rfft+peak)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic (generated on the device)" if args.device_synth else "synthetic",
-            "config": {"workload": (f"configs[1]: " if args.workload == "optimized" else f"variant '{args.workload}': ")
-                                   + f"{B} synthetic rx frames per GPU per step, {cfg.n_bands} bands, N={cfg.n_rx}, "
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (generated on the device)" if (args.device_synth or strong) else "synthetic",
+            "config": {"workload": wl + f"{cfg.n_bands} bands, N={cfg.n_rx}, "
                                    f"M={cfg.n_chirp}, IIR order {cfg.IIR_ORDER} (filtfilt) + FIR {cfg.FIR_TAPS}, "
                                    f"rfft({cfg.n_rx}) dB spectra "
                                    + ("stored" if want_spec else "not stored")
                                    + ", correlate, first_strong_peak, confidence fusion, Kalman over "
-                                   f"{S} streams" + (", RCCL all-gather of 64-B result records" if world > 1 else "")
+                                   f"{S} streams" + (", RCCL all-gather of 64-B result records" if use_dist else "")
                                    + (", IIR of the next step prefetched on a second stream" if pipeline else ""),
                        "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode,
                        "pipelined_iir": pipeline},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "band_kernel", "kernel_ms": kms["band"],
+                         "kernel": names[dom], "kernel_ms": cand[dom], "frames_per_launch": launch_frames,
                          "algorithmic_bytes_per_launch": bytes_per_frame * launch_frames,
-                         "note": "VALU/LDS-bound chain (~13 MFLOP/frame f64+f32): HBM fraction is low by construction"},
+                         "note": "algorithmic bytes of the whole chain (rx in, spectra + record out) over the longest "
+                                 "kernel's duration; the chain is bound by vector instruction issue and LDS "
+                                 "(~13 MFLOP/frame), so the HBM fraction is low by construction"
+                                 + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")},
             "kernel_ms": kms,
         }
-        if args.workload != "original" and args.mode == "named":
-            # what bounds this kernel: multiply-adds of the FIR and the matched filter against the vector peaks
-            # (float64 78.6 TFLOP/s, float32 157.3 TFLOP/s; the chain splits each by what the detector reads)
+        if strong:
+            out["config"]["total_frames"] = args.total_frames
+            out["config"]["frames_per_rank"] = counts
+        if args.workload in ("optimized", "realtime") and args.mode == "named" and not split:
+            # what bounds the single-frame band kernel: multiply-adds of the FIR and the matched filter against the
+            # vector peaks (float64 78.6 TFLOP/s, float32 157.3 TFLOP/s; the chain splits each by what the detector reads)
             nexact = cfg.half + cfg.min_delay - (cfg.n_chirp - 1)
             f64 = cfg.FIR_TAPS * (cfg.n_rx - nexact) + cfg.n_chirp * (cfg.n_corr - cfg.half - cfg.min_delay)
             f32 = cfg.FIR_TAPS * nexact + cfg.n_chirp * cfg.half
             per_launch = launch_frames * cfg.n_bands
             t_peak = per_launch * 2.0 * (f64 / 78.6e12 + f32 / 157.3e12)
             out["valu"] = {"kernel": "band_kernel", "f64_fma_per_frame_band": f64, "f32_fma_per_frame_band": f32,
-                           "seconds_at_vector_peak": t_peak, "frac_of_vector_peak": t_peak / band_s,
-                           "note": "supplementary: the band kernel is bound by vector instruction issue, not by HBM"
+                           "seconds_at_vector_peak": t_peak, "frac_of_vector_peak": t_peak / (kms["band"] / 1e3),
+                           "note": "supplementary: the single-frame band kernel is bound by vector instruction issue"
                                    + ("; its duration here includes the co-running prefetched IIR" if pipeline else "")}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "optimized":
-            out["cpu_baseline"] = cpu_baseline(cfg, eng.tables, rx_host, args.cpu_seconds, args.cpu_workers)
+        if world == 1 and not strong and not args.no_cpu_baseline and args.workload == "optimized":
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_runs, args.cpu_workers)
         print(json.dumps(out), flush=True)
     if use_dist:
         last = (counter[0] - 1) & 1
-        assert torch.equal(gathered[last][rank * B:(rank + 1) * B], recs[last])   # the gathered records hold this rank's shard
+        off = rank * Bmax
+        assert torch.equal(gathered[last][off:off + B], recs[last])   # the gathered records hold this rank's shard
         dist.barrier()
         dist.destroy_process_group()
 

@@ -58,20 +58,32 @@ def gather_records(rec_local: torch.Tensor, counts: Optional[List[int]] = None, 
     return torch.cat([out[r * cmax: r * cmax + c] for r, c in enumerate(counts)], dim=0)
 
 
-def gather_stream_records(rec_local: torch.Tensor, n_streams: int, group=None) -> torch.Tensor:
-    """Records of stream-sharded, time-major batches -> global time-major order [T*S, 64]."""
+def gather_stream_records(rec_local: torch.Tensor, n_streams: int, group=None,
+                          n_steps: Optional[int] = None) -> torch.Tensor:
+    """Records of stream-sharded, time-major batches -> global time-major order [T*S, 64].
+    ``n_steps`` (T) is needed when a rank may hold no stream at all (fewer streams than ranks): its contribution is
+    empty, so T cannot be read off its rows."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rec_local
     world = dist.get_world_size(group)
     bounds = shard_bounds(n_streams, world)
     s_r = [hi - lo for lo, hi in bounds]
-    t = rec_local.shape[0] // s_r[dist.get_rank(group)]
+    mine = s_r[dist.get_rank(group)]
+    if n_steps is None:
+        if mine == 0:
+            raise ValueError("gather_stream_records: this rank holds no stream; pass n_steps")
+        n_steps = rec_local.shape[0] // mine
+    t = int(n_steps)
+    if rec_local.shape[0] != t * mine:
+        raise ValueError(f"gather_stream_records: expected {t * mine} local rows, got {rec_local.shape[0]}")
     flat = gather_records(rec_local, [t * s for s in s_r], group)
     parts, off = [], 0
+    width = flat.shape[1]
     for s in s_r:
-        parts.append(flat[off:off + t * s].reshape(t, s, -1))
+        if s:
+            parts.append(flat[off:off + t * s].reshape(t, s, width))
         off += t * s
-    return torch.cat(parts, dim=1).reshape(t * n_streams, -1)
+    return torch.cat(parts, dim=1).reshape(t * n_streams, width)
 
 
 def process_sharded(engine, rx_global: torch.Tensor, n_streams: Optional[int] = None, kalman=None,
@@ -82,10 +94,19 @@ def process_sharded(engine, rx_global: torch.Tensor, n_streams: Optional[int] = 
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if n_streams:
+        if rx_global.shape[0] % n_streams:
+            raise ValueError("process_sharded: the batch must hold whole time steps of n_streams frames")
+        t = rx_global.shape[0] // n_streams
         local, (s0, s1) = local_stream_frames(rx_global, n_streams, rank, world)
-        rec, spec = engine.chain(local, n_streams=s1 - s0, kalman=kalman, want_spectra=want_spectra)
-        return gather_stream_records(rec, n_streams, group), spec
+        if s1 > s0:
+            rec, spec = engine.chain(local, n_streams=s1 - s0, kalman=kalman, want_spectra=want_spectra)
+        else:                                  # more ranks than streams: this rank contributes no rows
+            rec, spec = torch.empty((0, 64), dtype=torch.uint8, device=rx_global.device), None
+        return gather_stream_records(rec, n_streams, group, n_steps=t), spec
     lo, hi = shard_range(rx_global.shape[0], rank, world)
-    rec, spec = engine.chain(rx_global[lo:hi], want_spectra=want_spectra)
+    if hi > lo:
+        rec, spec = engine.chain(rx_global[lo:hi], want_spectra=want_spectra)
+    else:                                      # more ranks than frames
+        rec, spec = torch.empty((0, 64), dtype=torch.uint8, device=rx_global.device), None
     counts = [b - a for a, b in shard_bounds(rx_global.shape[0], world)]
     return gather_records(rec, counts, group), spec

@@ -52,7 +52,15 @@ def _worker(rank, world, port, q):
         rec = torch.full((4, 64), rank, dtype=torch.uint8)
         allr = gather_records(rec)
         ok3 = allr.shape == (8, 64) and bool((allr[:4] == 0).all()) and bool((allr[4:] == 1).all())
-        q.put((rank, ok1, ok2, ok3))
+        # fewer streams / frames than ranks: one rank contributes nothing
+        rx1 = torch.randn(3, 16, generator=g)                   # T = 3 steps of S = 1 stream
+        full1, _ = eng.chain(rx1, n_streams=1)
+        got1, _ = process_sharded(eng, rx1, n_streams=1)
+        rxf = torch.randn(1, 16, generator=g)                   # a single frame
+        fullf, _ = eng.chain(rxf)
+        gotf, _ = process_sharded(eng, rxf)
+        ok4 = torch.equal(got1, full1) and torch.equal(gotf, fullf)
+        q.put((rank, ok1, ok2, ok3, ok4))
     finally:
         dist.destroy_process_group()
 
@@ -68,10 +76,11 @@ def test_two_rank_gloo_sharding_and_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok1, ok2, ok3 in res:
+    for rank, ok1, ok2, ok3, ok4 in res:
         assert ok1, f"rank {rank}: frame-sharded records differ from the single-process run"
         assert ok2, f"rank {rank}: stream-sharded records differ from the single-process run"
         assert ok3, f"rank {rank}: equal-count gather is mis-ordered"
+        assert ok4, f"rank {rank}: a shard without streams or frames breaks the gather"
 
 
 def test_shard_bounds_cover_and_balance():
