@@ -131,10 +131,10 @@ __device__ __forceinline__ void bluestein9_round(int tid, const BandParams& p, u
 //   4608-point cyclic convolution yields both correlations, every lag) -> float32 maxima (signed over
 //   pos[min_delay:], absolute over every lag outside the blind zone) and the list of lags whose float32 value lies
 //   within 2 eps of them, eps being a bound on the float32 path's error.
-// exact_kernel, one 256-thread workgroup per (frame, band), float64: the noise window and every listed lag, exactly:
-//   FIR outputs from the float64 y, then the chirp dot products, both as sequential fused multiply-add sums (the
-//   operation order of the single-frame kernel).  The true extrema are among the re-evaluated lags, so peak index,
-//   SNR and amplitude are those of an all-float64 evaluation and do not depend on the partner frame.
+// exact_kernel, one wavefront per (frame, band), float64: the noise window and every listed lag, exactly: FIR outputs
+//   from the float64 y, then the chirp dot products, both as sequential fused multiply-add sums (the operation order
+//   of the single-frame kernel).  The true extrema are among the re-evaluated lags, so peak index, SNR and amplitude
+//   are those of an all-float64 evaluation and do not depend on the partner frame.
 // Reference: airSonar_optimized.py:193-194 (FIR), :290-303 (correlate), :200-219 (first_strong_peak), :666 (amplitude).
 
 // Block reduction of four values per thread (op 1: max, op 0: sum); every thread gets the four results.
@@ -324,16 +324,26 @@ __global__ __launch_bounds__(kF9NT, 7) void band2_kernel(BandParams p, int B) {
     STAMP(5);
 }
 
-// Exact float64 evaluation of one segment of lags [k0, k0 + nl) of one (frame, band): stage y, FIR -> band_sig window
-// (zero outside [0, N), as the 'same' crop leaves it), chirp dot products, fold into the running maximum (first index
-// on ties), the amplitude and the noise window.  Called by all 256 threads; returns after a barrier.
-constexpr int kExNT = 256;
-struct ExView { const double *gt64, *gc64; double *yw, *bw, *cv, *nw; float* nwf; int* cnt; B2Misc* misc; };
+// ---- exact_kernel: one wavefront per (frame, band), four independent wavefronts per workgroup, each with its own
+// LDS windows; a wavefront synchronises with itself only (its LDS operations execute in program order).
+constexpr int kExWaves = 4, kExNT = 64 * kExWaves;
+struct ExView { const double *gt64, *gc64; double *yw, *bw, *cv; };
+
+__device__ __forceinline__ void ex_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One 8-byte read of LDS that the compiler neither merges with its neighbours nor widens to a flat access.
+typedef const volatile __attribute__((address_space(3))) double lds_cv_f64;
+__device__ __forceinline__ double lds_read_f64(const double* p) { return *(lds_cv_f64*)p; }
 
 // acc[r] = sum_j x[r + j] * c[j], j < n rounded up to a multiple of T (c is zero beyond n, x finite), as sequential
-// fused multiply-add sums in ascending j.  x: LDS window, read in batches of R + T - 1 samples for R * T multiply-adds
-// (the LDS, shared by the four SIMDs of a compute unit, is what this kernel would otherwise be bound by); c: the
-// coefficient table in device memory, indexed uniformly across the wavefront (scalar loads).
+// fused multiply-add sums in ascending j.  x: LDS window, read in batches of R + T - 1 samples for R * T multiply-adds;
+// c: the coefficient table in device memory, indexed uniformly across the wavefront (scalar loads).  The window reads
+// are volatile so that they stay single 8-byte reads (ds_read_b64: 256 bytes per clock); merged into pairs
+// (ds_read2_b64) the same bytes take twice the LDS cycles.
 template <int R, int T> __device__ __forceinline__ void ex_dots(const double* x, const double* __restrict__ c, int n,
                                                                   double (&acc)[R]) {
 #pragma unroll
@@ -342,7 +352,7 @@ template <int R, int T> __device__ __forceinline__ void ex_dots(const double* x,
     for (int j = 0; j < n; j += T) {
         double xv[R + T - 1], cc[T];
 #pragma unroll
-        for (int t = 0; t < R + T - 1; ++t) xv[t] = x[j + t];
+        for (int t = 0; t < R + T - 1; ++t) xv[t] = lds_read_f64(x + j + t);
 #pragma unroll
         for (int t = 0; t < T; ++t) cc[t] = c[j + t];
 #pragma unroll
@@ -352,173 +362,154 @@ template <int R, int T> __device__ __forceinline__ void ex_dots(const double* x,
     }
 }
 
-// RF / RC: consecutive FIR outputs / lags per lane (sliding dot products: one LDS read of the signal per RF or RC
-// multiply-adds).  Long segments take 9 of each -- least LDS traffic, which is what bounds this kernel; segments of a
-// few lags take short chains on more lanes.  The summation order per output is the same for every RF / RC.
-template <int RF, int RC, int SLOT = 0>
+// Exact float64 evaluation of one segment of lags [k0, k0 + nl), nl <= kB2Seg, of one (frame, band) by one wavefront:
+// stage y, FIR -> band_sig window (zero outside [0, N), as the 'same' crop leaves it), chirp dot products into v.cv
+// (which overlays the y window), and the fold into the running signed maximum of pos[min_delay:] (first index on
+// ties) and the running max|corr| outside the blind zone.  RF / RC: consecutive FIR outputs / lags per lane (sliding dot products: one LDS read of the signal
+// per RF or RC multiply-adds); both are odd, so that the 8-byte reads of consecutive lanes fall into different LDS
+// banks; the summation order per output is the same for every RF / RC.
+template <int RF, int RC>
 __device__ __forceinline__ void exact_segment(const BandParams& p, const ExView& v, const double* y, int k0, int nl,
-                                              int tid) {
-    const int blk = blockIdx.x; (void)blk;
+                                              int lane, double& best, int& bidx, double& amp) {
     const int kstart = p.half + p.min_delay;
     const int nb0 = k0 - (p.M - 1);                          // band_sig index of window element 0
     const int nband = nl + p.M - 1;
     const int nfir = (nband + RF - 1) / RF, ncl = (nl + RC - 1) / RC;
-    for (int i = tid; i < p.b2_ywlen; i += kExNT) {
+    ex_wave_sync();                                          // the previous segment's reads of cv are done
+    for (int i = lane; i < p.b2_ywlen; i += 64) {
         const int n = nb0 - p.ypad + i;
         v.yw[i] = (n >= 0 && n < p.N) ? y[n] : 0.0;
     }
-    __syncthreads();
-    if (SLOT) STAMP(SLOT);
-    for (int l = tid; l < nfir; l += kExNT) {
+    ex_wave_sync();
+    for (int l = lane; l < nfir; l += 64) {
         double a[RF];
         ex_dots<RF, 8>(v.yw + RF * l, v.gt64, p.K, a);
 #pragma unroll
         for (int r = 0; r < RF; ++r) { const int n = nb0 + RF * l + r; v.bw[RF * l + r] = (n >= 0 && n < p.N) ? a[r] : 0.0; }
     }
-    for (int i = RF * nfir + tid; i < p.b2_bwlen; i += kExNT) v.bw[i] = 0.0;
-    __syncthreads();
-    if (SLOT) STAMP(SLOT + 1);
-    for (int l = tid; l < ncl; l += kExNT) {
+    for (int i = RF * nfir + lane; i < p.b2_bwlen; i += 64) v.bw[i] = 0.0;
+    ex_wave_sync();
+    for (int l = lane; l < ncl; l += 64) {
         double a[RC];
         ex_dots<RC, 8>(v.bw + RC * l, v.gc64, p.M, a);
 #pragma unroll
         for (int r = 0; r < RC; ++r) if (RC * l + r < nl) v.cv[RC * l + r] = a[r];
     }
-    __syncthreads();
-    if (SLOT) STAMP(SLOT + 2);
-    if (tid < 64) {
-        double best = -INFINITY, amp = 0.0; int bidx = 0x7fffffff;
-        for (int i = tid; i < nl; i += 64) {
-            const int k = k0 + i, qd = k - p.half;
-            if (qd >= 0 && qd < p.min_delay) continue;
-            const double x = v.cv[i], a = fabs(x);
-            amp = a > amp ? a : amp;
-            if (k >= kstart) {
-                if (x > best) { best = x; bidx = qd; }
-                const int w = qd - p.min_delay;
-                if (w < p.noise_n) { v.nw[w] = a; v.nwf[w] = (float)a; }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double b2 = __shfl_xor(best, o); const int i2 = __shfl_xor(bidx, o);
-            combine(best, bidx, b2, i2);
-            const double a2 = __shfl_xor(amp, o); amp = a2 > amp ? a2 : amp;
-        }
-        if (tid == 0) {
-            double mb = v.misc->best; int mi = v.misc->bidx;
-            combine(mb, mi, best, bidx);
-            v.misc->best = mb; v.misc->bidx = mi;
-            v.misc->amp = amp > v.misc->amp ? amp : v.misc->amp;
-        }
+    ex_wave_sync();
+    double b = -INFINITY, am = 0.0; int bi = 0x7fffffff;
+    for (int i = lane; i < nl; i += 64) {
+        const int k = k0 + i, qd = k - p.half;
+        if (qd >= 0 && qd < p.min_delay) continue;           // blind zone: zero by definition
+        const double x = v.cv[i], a = fabs(x);
+        am = a > am ? a : am;
+        if (k >= kstart && x > b) { b = x; bi = qd; }
     }
-    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double b2 = __shfl_xor(b, o); const int i2 = __shfl_xor(bi, o);
+        combine(b, bi, b2, i2);
+        const double a2 = __shfl_xor(am, o); am = a2 > am ? a2 : am;
+    }
+    combine(best, bidx, b, bi);
+    amp = am > amp ? am : amp;
 }
 
-__global__ __launch_bounds__(kExNT, 6) void exact_kernel(BandParams p) {
+__global__ __launch_bounds__(kExNT) void exact_kernel(BandParams p, int nfb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, blk = blockIdx.x, band = blk % p.nb;
-    STAMP(12);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wavefront-uniform: table reads become scalar loads
+    const int fb = blockIdx.x * kExWaves + wave;             // (frame, band) of this wavefront
+    if (fb >= nfb) return;                                   // wavefronts never wait for each other
+    const int band = fb % p.nb;
     ExView v;
     {
-        double* d = reinterpret_cast<double*>(smem);
-        const int nt_ = (p.kgroups + 1) * kR, nc_ = (p.mgroups + 1) * kR, nn = p.noise_n;
+        double* d = reinterpret_cast<double*>(smem) + (size_t)wave * (p.b2_ywlen + p.b2_bwlen);
+        const int nt_ = (p.kgroups + 1) * kR, nc_ = (p.mgroups + 1) * kR;
         v.gt64 = p.taps_rev + (size_t)band * nt_; v.gc64 = p.chirp + (size_t)band * nc_;
-        v.yw = d; d += p.b2_ywlen; v.bw = d; d += p.b2_bwlen; v.cv = d; d += (kB2Seg + 1) & ~1;
-        v.nw = d; d += nn; v.nwf = reinterpret_cast<float*>(d); d += (nn + 1) / 2;
-        v.cnt = reinterpret_cast<int*>(d); d += nn;
-        v.misc = reinterpret_cast<B2Misc*>(d);
-        if (tid == 0) {
-            v.misc->best = p.min_delay > 0 ? 0.0 : -INFINITY; v.misc->bidx = p.min_delay > 0 ? 0 : 0x7fffffff;   // pos[0] = 0 in the blind zone
-            v.misc->amp = 0.0; v.misc->med0 = 0.0; v.misc->med1 = 0.0;
-        }
+        v.yw = d; v.cv = d; v.bw = d + p.b2_ywlen;
     }
-    const double* y = p.d_in + (size_t)blk * p.N;
-    // the listed lags, read once: lane i of every wavefront holds entry i
-    const B2Det* det = p.det_out + blk;
+    const double* y = p.d_in + (size_t)fb * p.N;
+    // the listed lags, read once: lane i holds entry i
+    const B2Det* det = p.det_out + fb;
     const int nc = det->ncand;
-    const int lane = tid & 63;
     const int mine = (lane < nc && lane < kB2MaxCand) ? det->cand[lane] : 0x7fffffff;
-    // the noise window, then the listed lags (segments that start at a listed lag cover the listed lags behind it);
-    // an overflowing list means nothing is known, and every lag is evaluated
-    STAMP(13);
-    exact_segment<9, 4, 17>(p, v, y, p.half + p.min_delay, p.noise_n, tid);      // its first barrier publishes the tables
-    STAMP(14);
+    // pos[0] = 0 in the blind zone takes part in the argmax
+    double best = p.min_delay > 0 ? 0.0 : -INFINITY, amp = 0.0; int bidx = p.min_delay > 0 ? 0 : 0x7fffffff;
+    // ---- the noise window, exactly
+    const int kstart = p.half + p.min_delay, n = p.noise_n;
+    exact_segment<9, 5>(p, v, y, kstart, n, lane, best, bidx, amp);
+    double x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane * 4 + e; x[e] = i < n ? fabs(v.cv[i]) : INFINITY; }
+    // ---- the listed lags (segments that start at a listed lag cover the listed lags behind it); an overflowing list
+    // means nothing is known, and every lag is evaluated
     if (nc > kB2MaxCand) {
-        for (int k0 = 0; k0 < p.L; k0 += kB2Seg) exact_segment<9, 4>(p, v, y, k0, p.L - k0 < kB2Seg ? p.L - k0 : kB2Seg, tid);
+        for (int k0 = 0; k0 < p.L; k0 += kB2Seg)
+            exact_segment<9, 5>(p, v, y, k0, p.L - k0 < kB2Seg ? p.L - k0 : kB2Seg, lane, best, bidx, amp);
     } else {
         int done_below = 0;                                    // lags below it have been evaluated
         for (;;) {
             int lo = mine >= done_below ? mine : 0x7fffffff;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(lo, o); lo = x < lo ? x : lo; }
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(lo, o); lo = t < lo ? t : lo; }
             if (lo == 0x7fffffff) break;
             // how far the listed lags reach from lo inside one segment
             int hi = (mine >= lo && mine < lo + kB2Seg) ? mine : lo;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(hi, o); hi = x > hi ? x : hi; }
-            if (hi - lo >= 16) exact_segment<9, 4>(p, v, y, lo, hi - lo + 1, tid);
-            else exact_segment<5, 1>(p, v, y, lo, hi - lo + 1, tid);
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(hi, o); hi = t > hi ? t : hi; }
+            if (hi - lo >= 16) exact_segment<9, 5>(p, v, y, lo, hi - lo + 1, lane, best, bidx, amp);
+            else exact_segment<5, 1>(p, v, y, lo, hi - lo + 1, lane, best, bidx, amp);
             done_below = hi + 1;
         }
     }
-    // ---- median of the noise window (np.median: mean of the two middle order statistics): the first wavefront sorts
-    // the window, padded with +inf to 256 values, four per lane, by a bitonic network in registers
-    STAMP(15);
-    const int n = p.noise_n;
-    if (tid < 64) {
-        double x[4];
+    // ---- median of the noise window (np.median: mean of the two middle order statistics): the window, padded with
+    // +inf to 256 values, four per lane, sorted by a bitonic network in registers
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int i = tid * 4 + e; x[e] = i < n ? v.nw[i] : INFINITY; }
+    for (int k = 2; k <= 256; k <<= 1) {
 #pragma unroll
-        for (int k = 2; k <= 256; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
 #pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j >= 4) {
+                for (int e = 0; e < 4; ++e) {
+                    const int i = lane * 4 + e;
+                    const double o = __shfl_xor(x[e], j >> 2);
+                    const bool lower = (i & j) == 0, asc = (i & k) == 0;
+                    const double mn = fmin(x[e], o), mx = fmax(x[e], o);
+                    x[e] = (lower == asc) ? mn : mx;
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = tid * 4 + e;
-                        const double o = __shfl_xor(x[e], j >> 2);
-                        const bool lower = (i & j) == 0, asc = (i & k) == 0;
-                        const double mn = fmin(x[e], o), mx = fmax(x[e], o);
-                        x[e] = (lower == asc) ? mn : mx;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (e & j) continue;
-                        const int i = tid * 4 + e;
-                        const bool asc = (i & k) == 0;
-                        const double a = x[e], b = x[e | j];
-                        const double mn = fmin(a, b), mx = fmax(a, b);
-                        x[e] = asc ? mn : mx; x[e | j] = asc ? mx : mn;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    if (e & j) continue;
+                    const int i = lane * 4 + e;
+                    const bool asc = (i & k) == 0;
+                    const double a = x[e], b = x[e | j];
+                    const double mn = fmin(a, b), mx = fmax(a, b);
+                    x[e] = asc ? mn : mx; x[e | j] = asc ? mx : mn;
                 }
             }
         }
-        // ranks (n - 1) / 2 and n / 2 of the sorted sequence
-        const int r0 = (n - 1) / 2, r1 = n / 2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = tid * 4 + e;
-            if (i == r0) v.misc->med0 = x[e];
-            if (i == r1) v.misc->med1 = x[e];
-        }
     }
-    __syncthreads();
-    STAMP(16);
+    // ranks (n - 1) / 2 and n / 2 of the sorted sequence
+    const int r0 = (n - 1) / 2, r1 = n / 2;
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double a = __shfl(x[e], r0 >> 2), b = __shfl(x[e], r1 >> 2);
+        if ((r0 & 3) == e) m0 = a;
+        if ((r1 & 3) == e) m1 = b;
+    }
     // ---- SNR, gate, record (first_strong_peak, airSonar_optimized.py:209-219)
-    if (tid == 0 && p.res_out) {
-        const B2Misc* m = v.misc;
+    if (lane == 0 && p.res_out) {
         BandRes r;
-        r.amplitude = m->amp; r.pad = 0;
-        const double med = (m->med0 + m->med1) / 2.0, noise_floor = med * med;
-        const double peak_power = m->best * m->best;
+        r.amplitude = amp; r.pad = 0;
+        const double med = (m0 + m1) / 2.0, noise_floor = med * med;
+        const double peak_power = best * best;
         double snr = 0.0;
         if (noise_floor > 0.0) snr = 10.0 * log10(peak_power / noise_floor);
         if (snr < p.snr_gate) { r.peak_idx = -1; r.snr_db = 0.0; }
-        else                  { r.peak_idx = m->bidx; r.snr_db = snr; }
-        p.res_out[blk] = r;
+        else                  { r.peak_idx = bidx; r.snr_db = snr; }
+        p.res_out[fb] = r;
     }
 }
 
@@ -616,7 +607,8 @@ int launch_band2_pair(const BandParams& p, int B, hipStream_t s) {
 int launch_band2_exact(const BandParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (!p.band2 || !p.d_in || !p.res_out || !p.det_out) return -1;
-    hipLaunchKernelGGL(exact_kernel, dim3((unsigned)B * p.nb), dim3(kExNT), p.b2_exact_smem_bytes, s, p);
+    const int nfb = B * p.nb;
+    hipLaunchKernelGGL(exact_kernel, dim3((unsigned)((nfb + kExWaves - 1) / kExWaves)), dim3(kExNT), p.b2_exact_smem_bytes, s, p, nfb);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -156,9 +156,7 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
         p.b2_off_red = o;  o += 2 * (kF9NT / 64) * 4 * 8;
         p.b2_off_misc = o; o += 16;
         p.b2_smem_bytes = o;
-        const int nn1 = nn > 0 ? nn : 1;
-        p.b2_exact_smem_bytes = 8 * (p.b2_ywlen + p.b2_bwlen +
-                                     align_up(kB2Seg, 2) + nn1 + (nn1 + 1) / 2 + nn1) + align_up((int)sizeof(B2Misc), 16);
+        p.b2_exact_smem_bytes = 4 * 8 * (p.b2_ywlen + p.b2_bwlen);        // four wavefronts, each with its two windows
         const bool fits = detector == 0 && p.L <= kF9M && 2 * p.ybuf_len * 4 <= kF9Slots * 8 && N <= kF9NT * kR &&
                           nn >= 1 && p.half + min_delay + nn <= p.L && nn <= kB2Seg && nn <= 256 &&
                           ceil_div(kB2Seg + M - 1, kB2R) <= 256 && p.b2_exact_smem_bytes <= 64 * 1024;
