@@ -52,8 +52,11 @@ def parse():
                          "multi-GPU code path on a one-GPU box)")
     ap.add_argument("--device-synth", action="store_true",
                     help="generate the batch in device memory (every frame distinct, no upload)")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="batches in flight: consecutive steps run on this many streams (one library handle each), "
+                         "only their Kalman stages ordered; 1 = one stream, the next step's IIR prefetched beside it")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="do not start the next step's IIR on the engine's own stream during the current step")
+                    help="one stream, nothing overlapped: every step runs its kernels one after the other")
     ap.add_argument("--mode", choices=("named", "full"), default="named",
                     help="'named': the chain the headline metric names (filter + rfft + first_strong_peak + fusion); "
                          "'full': with the reference's Hilbert-envelope branch (secondary measurement)")
@@ -161,6 +164,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # the JSON line must be the only thing on stdout: libraries loaded below (the collective library prints a banner
+    # there) get stderr as their file descriptor 1, and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -170,15 +178,11 @@ def main():
     from dsp_amd.config import optimized_config, original_config, realtime_config, twopeak_config
     from dsp_amd.dist import shard_bounds
     from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.lanes import ChainLanes
     from dsp_amd.synth import synth_frames
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-
     cfg = {"optimized": optimized_config, "original": original_config, "realtime": realtime_config,
            "twopeak": twopeak_config}[args.workload]()
     eng = EchoEngine(cfg, dev)
@@ -201,32 +205,85 @@ def main():
             rx = torch.from_numpy(rx_host).to(dev)
             if B > 4096:
                 rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
-    S = _largest_divisor(B, N_STREAMS)                      # 64 whenever the batch is a multiple of it
+    # Batches in flight.  Up to the fusion a batch depends on nothing but its frames, and every kernel of the chain
+    # keeps one unit of the GPU busy at a time, so consecutive steps run on `lanes` streams (ChainLanes: one library
+    # handle each) with only their Kalman stages ordered.  The sharded job submits its shard in chunks the same way.
+    # With one lane the step runs on one stream and only the next step's IIR is started beside it (chain_prefetch).
+    n_lanes = 1 if args.no_pipeline else max(1, args.lanes)
+    CHUNK = 8192
+    if strong and n_lanes > 1:
+        chunks = [(c, min(c + CHUNK, B)) for c in range(0, B, CHUNK)]
+        import math
+        S = _largest_divisor(math.gcd(B, CHUNK) if B > CHUNK else B, N_STREAMS)
+    else:
+        chunks = [(0, B)]
+        S = _largest_divisor(B, N_STREAMS)                  # 64 whenever the batch is a multiple of it
     kal = BatchedKalman(eng, S)
-    eng.reserve(B)
+    lanes = ChainLanes(eng, n_lanes) if n_lanes > 1 else None
+    if lanes is not None:
+        lanes.reserve(min(B, CHUNK) if strong else B)
+    else:
+        eng.reserve(B)
+    if lanes is not None:
+        # the lanes' streams take their hardware queues first (one untimed batch each), the collective library's
+        # streams after them: created the other way round, lanes ended up sharing a queue and ran one after the other
+        warm = torch.empty((min(B, 64), 64), dtype=torch.uint8, device=dev)
+        for _ in range(n_lanes):
+            lanes.submit(rx[:warm.shape[0]], want_spectra=False, out=warm, mode=args.mode)
+        lanes.join()
+        torch.cuda.synchronize(dev)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     want_spec = not args.no_spectra
-    # two record buffers: with several ranks the all-gather of step k is asynchronous and only has to be complete
-    # before step k+2 writes the same buffer again, so the collective never stalls the compute stream.  Uneven shards
-    # are padded to the largest one inside the buffer the collective sends.
-    send = [torch.zeros((Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # Output buffers, one set per lane (at least two): with several ranks the all-gather of step k is asynchronous and
+    # only has to be complete before the step that writes the same buffer again, so the collective never stalls the
+    # compute streams.  Uneven shards are padded to the largest one inside the buffer the collective sends.
+    nbuf = max(2, n_lanes) if not strong else 2
+    send = [torch.zeros((Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     recs = [b[:B] for b in send]
-    spec = torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
-    gathered = [torch.empty((world * Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
-    works = [None, None]
+    nspec = 1 if (strong or n_lanes == 1) else nbuf         # the sharded job's spectra are one array per rank
+    specs = [torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
+             for _ in range(nspec)]
+    gathered = [torch.empty((world * Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if use_dist else None
+    works = [None] * nbuf
     counter = [0]
-
-    # Steady-state pipelining: the input of step k+1 is resident, so its zero-phase IIR (a sequential recurrence that
-    # leaves the arithmetic units idle) is started on the engine's own stream as soon as step k has been issued.
-    # Each step consumes one prefetched IIR and issues one, so K timed steps do the work of K full chains.
-    # (A call of eight or more internal passes -- the sharded job -- pipelines its own passes the same way.)
-    pipeline = (not args.no_pipeline and not strong
+    pipeline = (lanes is None and not args.no_pipeline and not strong
                 and B <= (16384 if args.workload in ("optimized", "realtime") else 4096))
 
+    owed = []                                               # (buffer, lane stream) of batches not gathered yet
+
+    def gather_one():
+        b, st = owed.pop(0)
+        if os.environ.get("ECHO_BENCH_NO_GATHER", "0") == "1":
+            return
+        with torch.cuda.stream(st):
+            works[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
+
     def step():
-        buf = counter[0] & 1
+        buf = counter[0] % nbuf
         counter[0] += 1
         if works[buf] is not None:
             works[buf].wait()
+        spec = specs[buf % nspec]
+        if lanes is not None:
+            for lo_, hi_ in chunks:
+                ev = lanes.submit(rx[lo_:hi_], n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf][lo_:hi_],
+                                  spec_out=spec[lo_:hi_] if want_spec else None, mode=args.mode)
+            if use_dist:
+                if strong:
+                    lanes.join()                        # a step of the sharded job ends with the gather of the whole shard
+                    works[buf] = dist.all_gather_into_tensor(gathered[buf], send[buf], async_op=True)
+                else:
+                    # The gather of a batch is issued from the batch's own lane, n_lanes - 1 steps later (the rest at
+                    # the fence): by then every lane's newer work is queued behind work that cannot start before this
+                    # batch is done anyway, so the collective's wait for the batch -- its stream shares one of the few
+                    # hardware queues with some lane -- holds nothing back.
+                    owed.append((buf, lanes.last_stream))
+                    if len(owed) >= n_lanes:
+                        gather_one()
+            return
         eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
         if pipeline:
             eng.chain_prefetch(rx)
@@ -234,6 +291,10 @@ def main():
             works[buf] = dist.all_gather_into_tensor(gathered[buf], send[buf], async_op=True)
 
     def fence():
+        while owed:
+            gather_one()
+        if lanes is not None:
+            lanes.join()
         for w in works:
             if w is not None:
                 w.wait()
@@ -245,17 +306,35 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    eng.set_profiling(min(args.steps, 64))
+    # kernel durations by HIP events on the calls' own streams, inside the timed region.  Event records keep a stream's
+    # kernels from running back to back, so only a sample of the calls is timed: every fourth call of the first lane
+    # (every call on a single stream).
+    prof_on = os.environ.get("ECHO_BENCH_NOPROF", "0") != "1"
+    if prof_on:
+        eng.set_profiling(min(args.steps, 64), every=4 if lanes is not None else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0                      # host time to queue the steps (the GPU runs behind)
     fence()
     dt = time.perf_counter() - t0
-    kms = eng.last_kernel_ms()
+    kms = eng.last_kernel_ms() if prof_on else {k: 1e-9 for k in ("iir", "band", "spec", "fuse", "pair", "exact")}
     eng.set_profiling(0)
     if pipeline:
         kms["iir_wait"] = kms["iir"]           # on the caller's stream only the wait for the prefetched IIR remains
         kms["iir"] = eng.prefetch_ms()         # device time of the IIR kernel on the engine's stream
+    kms_serial = None
+    if lanes is not None and prof_on and not strong:
+        # outside the timed region: the same kernels one after the other on one stream, every call timed.  With several
+        # batches in flight a kernel's duration above is stretched by the other lanes' kernels running beside it;
+        # these are the durations each kernel has with the GPU to itself.
+        eng.set_profiling(6)
+        for _ in range(6):
+            eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), want_spectra=want_spec, out=recs[0], spec_out=specs[0],
+                      mode=args.mode)
+        torch.cuda.synchronize(dev)
+        kms_serial = eng.last_kernel_ms()
+        eng.set_profiling(0)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,6 +348,8 @@ def main():
         # the first pass of each call
         if args.workload in ("original", "twopeak"):
             launch_frames = min(B, 4096)
+        elif lanes is not None and strong:
+            launch_frames = min(B, CHUNK)
         else:
             launch_frames = 8192 if B >= 65536 and os.environ.get("ECHO_INNER_PIPELINE", "1") != "0" else min(B, 16384)
         # the dominant kernel: the longest of the chain's kernels by its event-measured duration in this run (the
@@ -310,9 +391,11 @@ def main():
                                    + ("stored" if want_spec else "not stored")
                                    + ", correlate, first_strong_peak, confidence fusion, Kalman over "
                                    f"{S} streams" + (", RCCL all-gather of 64-B result records" if use_dist else "")
-                                   + (", IIR of the next step prefetched on a second stream" if pipeline else ""),
+                                   + (", IIR of the next step prefetched on a second stream" if pipeline else "")
+                                   + (f", {n_lanes} batches in flight on {n_lanes} streams (Kalman stages in order)"
+                                      if lanes is not None else ""),
                        "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode,
-                       "pipelined_iir": pipeline},
+                       "pipelined_iir": pipeline, "lanes": n_lanes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": names[dom], "kernel_ms": cand[dom], "frames_per_launch": launch_frames,
@@ -320,9 +403,28 @@ def main():
                          "note": "algorithmic bytes of the whole chain (rx in, spectra + record out) over the longest "
                                  "kernel's duration; the chain is bound by vector instruction issue and LDS "
                                  "(~13 MFLOP/frame), so the HBM fraction is low by construction"
-                                 + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")},
+                                 + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")
+                                 + (f"; {n_lanes} batches are in flight, so this kernel's duration (first lane's calls, "
+                                    "every fourth timed) is stretched by the other lanes' kernels running beside it "
+                                    "and exceeds ms_per_step: 'unshared' prices the same launch at the duration the "
+                                    "kernel has with the GPU to itself" if lanes is not None else "")},
             "kernel_ms": kms,
+            "host_issue_ms_per_step": t_issue / args.steps * 1e3,
         }
+        if kms_serial is not None:
+            cs = {"iir": kms_serial["iir"], "spec": kms_serial["spec"]}
+            if kms_serial.get("pair", 0.0) > 0.0:
+                cs.update({"pair": kms_serial["pair"], "exact": kms_serial["exact"]})
+            else:
+                cs["band"] = kms_serial["band"]
+            ds = max(cs, key=cs.get)
+            a2 = bytes_per_frame * launch_frames / (cs[ds] / 1e3) / 1e9
+            out["roofline"]["unshared"] = {"kernel": names[ds], "kernel_ms": cs[ds], "achieved": a2,
+                                           "frac": a2 / HBM_PEAK_GBPS, "kernel_ms_all": kms_serial,
+                                           "note": "measured after the timed region: 6 calls on one stream, nothing overlapped"}
+            out["roofline"]["whole_chain"] = {"achieved": bytes_per_frame * frames / dt / 1e9,
+                                              "frac": bytes_per_frame * frames / dt / 1e9 / HBM_PEAK_GBPS,
+                                              "note": "algorithmic bytes per second of the whole job (value x bytes per frame)"}
         if strong:
             out["config"]["total_frames"] = args.total_frames
             out["config"]["frames_per_rank"] = counts
@@ -340,9 +442,10 @@ def main():
                                    + ("; its duration here includes the co-running prefetched IIR" if pipeline else "")}
         if world == 1 and not strong and not args.no_cpu_baseline and args.workload == "optimized":
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_runs, args.cpu_workers)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if use_dist:
-        last = (counter[0] - 1) & 1
+        last = (counter[0] - 1) % nbuf
         off = rank * Bmax
         assert torch.equal(gathered[last][off:off + B], recs[last])   # the gathered records hold this rank's shard
         dist.barrier()

@@ -18,7 +18,7 @@ EXPORTS = [
     "echo_synth_frames", "echo_chain", "echo_chain_full", "echo_chain_prefetch", "echo_prefetch_ms", "echo_graph_create", "echo_graph_launch", "echo_graph_destroy",
     "echo_set_profiling", "echo_last_kernel_ms", "echo_chain_noalloc", "echo_noalloc_max_frames",
     "echo_spectrum_rows", "echo_xcorr", "echo_envelope_rows", "echo_band_confidence", "echo_normalize_confidences",
-    "echo_kalman_update_qr", "echo_chain_wave", "echo_kernel_times",
+    "echo_kalman_update_qr", "echo_chain_wave", "echo_kernel_times", "echo_chain_ordered", "echo_set_profiling_every",
 ]
 
 
@@ -72,6 +72,8 @@ def load():
     lib.echo_band_confidence.argtypes = [P, P, P, P, P, I, P]
     lib.echo_normalize_confidences.argtypes = [P, P, I, I, P]
     lib.echo_kalman_update_qr.argtypes = [P, P, P, P, P, P, I, I, C.c_double, C.c_double, P]
+    lib.echo_chain_ordered.argtypes = [P, P, P, P, P, P, P, I, I, I, P, P, P]
+    lib.echo_set_profiling_every.argtypes = [P, I, I]
     lib.echo_kernel_times.argtypes = [P, C.POINTER(C.c_float), I]
     lib.echo_chain_wave.argtypes = [P, P, P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain_noalloc.argtypes = [P, P, P, P, P, P, P, I, I, P]

@@ -164,7 +164,39 @@ __device__ __forceinline__ void b2_reduce4(double (&v)[4], const int (&ops)[4], 
 // the addresses of a later phase out of the registers of an earlier one.
 #define ECHO_OPAQUE(x) asm volatile("" : "+v"(x))
 
-__global__ __launch_bounds__(kF9NT, 7) void band2_kernel(BandParams p, int B) {
+// Packed float32 arithmetic over the two frames of a pair: element x of a v2f belongs to the first frame, y to the
+// second (v_pk_fma_f32: two multiply-adds per instruction).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f lds_read_v2f(const float2* q) {
+    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_t;
+    const unsigned long long u = *(lds_u64_t)q;              // one ds_read_b64, never merged with its neighbour
+    return __builtin_bit_cast(v2f, u);
+}
+
+// acc[r] = sum_j in[r + j] * c[j] for both frames at once, j < ngroups * kR in ascending order (the order of the
+// single-frame kernel's float32 sums).  in: interleaved (frame A, frame B) samples in LDS, lane stride kR elements of
+// 8 bytes (conflict-free); c: the (c, c) pairs in device memory, indexed uniformly (scalar loads).
+__device__ __forceinline__ void sliding_dot_pk(const float2* in, const float2* __restrict__ c, int ngroups, v2f (&acc)[kR]) {
+    v2f w[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { w[r] = lds_read_v2f(in + r); acc[r] = v2f{0.f, 0.f}; }
+#pragma unroll 1
+    for (int g = 0; g < ngroups; ++g) {
+        const float2* nx = in + (g + 1) * kR;
+        v2f cg[kR];
+#pragma unroll
+        for (int t = 0; t < kR; ++t) { const float2 q = c[g * kR + t]; cg[t] = v2f{q.x, q.y}; }
+#pragma unroll
+        for (int t = 0; t < kR; ++t) {
+#pragma unroll
+            for (int r = 0; r < kR; ++r) acc[r] = __builtin_elementwise_fma(w[(r + t) % kR], cg[t], acc[r]);
+            w[t] = lds_read_v2f(nx + t);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kF9NT, 5) void band2_kernel(BandParams p, int B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tid = threadIdx.x;
     const int blk = blockIdx.x;
@@ -173,52 +205,49 @@ __global__ __launch_bounds__(kF9NT, 7) void band2_kernel(BandParams p, int B) {
     STAMP(0);
     const bool have1 = 2 * pair + 1 < B;
     float2* fft = reinterpret_cast<float2*>(smem);
-    float* ybuf = reinterpret_cast<float*>(smem);                     // both frames' FIR inputs, inside the transform buffer
-    float* ct32 = reinterpret_cast<float*>(smem + p.b2_off_ct32);
+    float2* ybuf = reinterpret_cast<float2*>(smem);                   // both frames' FIR inputs, interleaved, inside the transform buffer
     double* red = reinterpret_cast<double*>(smem + p.b2_off_red);
     int* ncand = reinterpret_cast<int*>(smem + p.b2_off_misc);        // [2]
     const int kstart = p.half + p.min_delay;
-    {
-        const int nt_ = (p.kgroups + 1) * kR;
-        for (int i = tid; i < nt_; i += kF9NT) ct32[i] = (float)p.taps_rev[(size_t)band * nt_ + i];
-        if (tid < 2) ncand[tid] = 0;
+    if (tid < 2) ncand[tid] = 0;
+    if (p.b2_stagger > 0 && blk < p.b2_stagger) {            // DEV PROBE: de-phase the first round of workgroups
+        const int units = blk & 7;
+        for (int u = 0; u < units; ++u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(45); }
     }
-    // ---- y of both frames, rounded to float32, into LDS: frame f at ybuf + f * ybuf_len
+    // ---- y of both frames, rounded to float32, into LDS: sample n of (frame A, frame B) at ybuf[n + ypad]
     double ymax = 0.0;
     {
         const double* y0 = p.d_in + ((size_t)(2 * pair) * p.nb + band) * p.N;
         const double* y1 = y0 + (size_t)p.nb * p.N;
-        constexpr int kBatch = 16;                           // 2 * ybuf_len <= 16 * 576 for the frame lengths this kernel takes: one round trip
-        const int total = 2 * p.ybuf_len;
-        for (int i0 = tid; i0 < total; i0 += kBatch * kF9NT) {
-            double t[kBatch];
+        constexpr int kBatch = 8;                            // ybuf_len <= 8 * 576 for the frame lengths this kernel takes: one round trip
+        for (int i0 = tid; i0 < p.ybuf_len; i0 += kBatch * kF9NT) {
+            double t0[kBatch], t1[kBatch];
 #pragma unroll
             for (int e = 0; e < kBatch; ++e) {
-                const int i = i0 + e * kF9NT;
-                const int f = i >= p.ybuf_len ? 1 : 0, n = i - f * p.ybuf_len - p.ypad;
-                t[e] = (i < total && n >= 0 && n < p.N && (f == 0 || have1)) ? (f ? y1 : y0)[n] : 0.0;
+                const int i = i0 + e * kF9NT, n = i - p.ypad;
+                const bool in = i < p.ybuf_len && n >= 0 && n < p.N;
+                t0[e] = in ? y0[n] : 0.0;
+                t1[e] = (in && have1) ? y1[n] : 0.0;
             }
 #pragma unroll
             for (int e = 0; e < kBatch; ++e)
-                if (i0 + e * kF9NT < total) {
-                    ybuf[i0 + e * kF9NT] = (float)t[e];
-                    const double a = fabs(t[e]); ymax = a > ymax ? a : ymax;
+                if (i0 + e * kF9NT < p.ybuf_len) {
+                    ybuf[i0 + e * kF9NT] = mk2((float)t0[e], (float)t1[e]);
+                    const double a0 = fabs(t0[e]), a1 = fabs(t1[e]);
+                    ymax = a0 > ymax ? a0 : ymax; ymax = a1 > ymax ? a1 : ymax;
                 }
         }
     }
     __syncthreads();
     STAMP(1);
-    // ---- float32 FIR of both frames
-    float acc[2][kR];
+    // ---- float32 FIR of both frames: acc[r] = (band_sig_A[n0 + r], band_sig_B[n0 + r])
+    v2f acc[kR];
     {
         const int n0 = tid * kR;
+        if (n0 < p.N) sliding_dot_pk(ybuf + n0, p.taps32x2 + (size_t)band * ((p.kgroups + 1) * kR), p.kgroups, acc);
+        else {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            if (n0 < p.N) sliding_dot_ff(ybuf + f * p.ybuf_len + n0, ct32, p.kgroups, acc[f]);
-            else {
-#pragma unroll
-                for (int r = 0; r < kR; ++r) acc[f][r] = 0.f;
-            }
+            for (int r = 0; r < kR; ++r) acc[r] = v2f{0.f, 0.f};
         }
     }
     __syncthreads();                                       // every lane has read its inputs: the buffer may be overwritten
@@ -233,7 +262,7 @@ __global__ __launch_bounds__(kF9NT, 7) void band2_kernel(BandParams p, int B) {
             const int n = n0 + r;
             if (n >= kF9M) continue;
             const bool in = n < p.N;
-            const float a = in ? acc[0][r] : 0.f, b = in ? acc[1][r] : 0.f;
+            const float a = in ? acc[r].x : 0.f, b = in ? acc[r].y : 0.f;
             fft[pos9(n)] = mk2(a, b);
             ss += (double)a * (double)a + (double)b * (double)b;
         }

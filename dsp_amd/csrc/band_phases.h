@@ -108,9 +108,11 @@ struct BandParams {
     // of the noise window and of every lag that can be the maximum
     int band2;                       // configuration fits the pair kernel
     const float2* f9ghat;            // [nb][4608] FFT of the reversed chirp / 4608, pass order of the 4608-point transform
+    const float2* taps32x2;          // [nb][(kgroups + 1) * kR] reversed FIR taps in float32, each as the pair (c, c)
     double eps_fir[3];               // per band: bound on the float32 FIR's contribution to a lag's error, per unit max|y|
     double eps_fft[3];               // per band: bound on the float32 transforms' contribution, per unit ||band_sig pair||_2
     int b2_off_ct32, b2_off_red, b2_off_misc, b2_smem_bytes;   // LDS of the pair kernel behind the transform buffer
+    int b2_stagger;                  // DEV PROBE
     int b2_ywlen, b2_bwlen;          // exact kernel: doubles of the y and band_sig windows of one segment
     int b2_exact_smem_bytes;
     struct B2Det* det_out;           // [B][nb] float32 maxima and candidate lags, pair kernel -> exact kernel

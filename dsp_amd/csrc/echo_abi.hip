@@ -73,7 +73,7 @@ struct EchoHandle {
     // device constant tables
     double *d_b = nullptr, *d_a = nullptr, *d_zi = nullptr, *d_taps_rev = nullptr, *d_chirp = nullptr;
     float2 *d_bw = nullptr, *d_bhat = nullptr, *d_tw = nullptr, *d_post = nullptr;
-    float2 *d_f9tw9 = nullptr, *d_f9twa = nullptr, *d_f9twb = nullptr, *d_f9bhat = nullptr, *d_f9ghat = nullptr;
+    float2 *d_f9tw9 = nullptr, *d_f9twa = nullptr, *d_f9twb = nullptr, *d_f9bhat = nullptr, *d_f9ghat = nullptr, *d_taps32x2 = nullptr;
     int use_band2 = 1;                     // ECHO_BAND2=0: the named chain keeps the single-frame band kernel
     // grow-only scratch, sized for cap_frames frames
     int cap_frames = 0;
@@ -92,6 +92,7 @@ struct EchoHandle {
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
     int prof_slots = 0, prof_used = 0;
+    int prof_every = 1, prof_calls = 0;    // every prof_every-th armed call is timed (event records keep kernels of one stream apart)
     std::vector<char> prof_pair;           // per slot: the band stage ran as pair kernel + exact kernel (event 5 recorded)
     bool capturing = false;                // inside echo_graph_create's stream capture
     int live_graphs = 0;                   // recorded graphs hold pointers into the scratch: it must not move while > 0
@@ -399,6 +400,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         }
         if (h->base.band2) {
             up(dev_upload(&h->d_f9ghat, t.f9ghat.data(), t.f9ghat.size()));
+            up(dev_upload(&h->d_taps32x2, t.taps32x2.data(), t.taps32x2.size()));
             if (rc == ECHO_OK) rc = band2_kernel_prepare(h->base.b2_smem_bytes, h->base.b2_exact_smem_bytes);
         }
         if (const char* pad = std::getenv("ECHO_BAND_SMEM_PAD")) h->base.smem_bytes += std::atoi(pad);   // development: occupancy experiments
@@ -452,7 +454,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->base.bw = h->d_bw; h->base.bhat = h->d_bhat; h->base.tw = h->d_tw; h->base.post = h->d_post;
     h->base.uk = h->d_uk;
     h->base.f9tw9 = h->d_f9tw9; h->base.f9twa = h->d_f9twa; h->base.f9twb = h->d_f9twb; h->base.f9bhat = h->d_f9bhat;
-    h->base.f9ghat = h->d_f9ghat;
+    h->base.f9ghat = h->d_f9ghat; h->base.taps32x2 = h->d_taps32x2;
     h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
@@ -465,7 +467,7 @@ void echo_destroy(EchoHandle* h) {
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
-                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_cfg, h->d_cfw2, h->d_cftw};
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
@@ -489,10 +491,17 @@ int echo_reserve(EchoHandle* h, int max_frames) {
     return ensure_scratch(h, std::min(max_frames, h->max_chunk));
 }
 
+int echo_set_profiling_every(EchoHandle* h, int slots, int every) {
+    if (every < 1) return ECHO_ERR_INVALID;
+    const int rc = echo_set_profiling(h, slots);
+    if (rc == ECHO_OK) h->prof_every = every;
+    return rc;
+}
+
 int echo_set_profiling(EchoHandle* h, int slots) {
     if (!h || slots < 0) return ECHO_ERR_INVALID;
     h->prof = slots > 0;
-    h->prof_used = 0;
+    h->prof_used = 0; h->prof_every = 1; h->prof_calls = 0;
     while ((int)h->ev.size() < kEvPerSlot * slots) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
@@ -852,9 +861,15 @@ int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_windo
 // grown on demand.  With ext nothing is allocated, no prefetched IIR is consumed and no timing events are recorded.
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
-                      double* quality, const Scratch* ext = nullptr, double* corr_out = nullptr) {
+                      double* quality, const Scratch* ext = nullptr, double* corr_out = nullptr,
+                      hipEvent_t kal_wait = nullptr, hipEvent_t kal_done = nullptr) {
     if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
-    if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
+    if (h && B == 0) {                                     // empty batch: nothing to do but to pass the Kalman order on
+        hipStream_t s0 = static_cast<hipStream_t>(stream);
+        if (kal_wait && hipStreamWaitEvent(s0, kal_wait, 0) != hipSuccess) return ECHO_ERR_HIP;
+        if (kal_done && hipEventRecord(kal_done, s0) != hipSuccess) return ECHO_ERR_HIP;
+        return ECHO_OK;
+    }
     if (!h || !rx || !out || B < 0) return ECHO_ERR_INVALID;
     if (full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) return ECHO_ERR_UNSUPPORTED;
     const bool kal = kalman_x || kalman_p || kalman_init;
@@ -890,7 +905,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         if (rc) return rc;
         if (full) { rc = ensure_full_scratch(h, n); if (rc) return rc; }
         const Scratch& sc = ext ? *ext : h->sc;
-        const bool prof = !ext && h->prof && f0 == 0 && h->prof_used < h->prof_slots;
+        const bool prof = !ext && h->prof && f0 == 0 && h->prof_used < h->prof_slots &&
+                          (h->prof_calls++ % h->prof_every) == 0;
         hipEvent_t* ev = prof ? &h->ev[kEvPerSlot * h->prof_used] : nullptr;
         bool pair_timed = false;
         if (prof) (void)hipEventRecord(ev[0], s);
@@ -984,6 +1000,9 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         rc = launch_fuse(fp, s);
         if (rc) return rc;
         if (kal) {
+            // the Kalman state is the only thing a batch inherits from the one before: a caller running batches on
+            // several streams orders this stage alone
+            if (kal_wait && f0 == 0 && hipStreamWaitEvent(s, kal_wait, 0) != hipSuccess) return ECHO_ERR_HIP;
             KalmanParams k;
             k.x = kalman_x; k.p = kalman_p; k.init = kalman_init; k.z = sc.fused; k.valid = sc.vany;
             k.out = nullptr; k.rec = out + f0; k.S = n_streams; k.T = n / n_streams;
@@ -1003,7 +1022,17 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         (void)hipEventRecord(h->chain_end[h->chain_gen], s);
         h->chain_end_set[h->chain_gen] = true;
     }
+    if (kal_done && hipEventRecord(kal_done, s) != hipSuccess) return ECHO_ERR_HIP;
     return ECHO_OK;
+}
+
+int echo_chain_ordered(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
+                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, int full, void* stream,
+                       void* kalman_wait_event, void* kalman_done_event) {
+    if (!kalman_x || !kalman_p || !kalman_init) return ECHO_ERR_INVALID;      // without a Kalman stage there is nothing to order
+    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, full != 0, nullptr,
+                      nullptr, nullptr, static_cast<hipEvent_t>(kalman_wait_event),
+                      static_cast<hipEvent_t>(kalman_done_event));
 }
 
 int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,

@@ -19,6 +19,19 @@ constexpr int kF9Slots = kF9M + kF9M / 8;          // 5184 float2 = 41472 bytes
 
 ECHO_HD int pos9(int e) { return e + (e >> 3); }
 
+// One complex element from the transform buffer in LDS.  On the device the read is a volatile 8-byte LDS read, which
+// keeps it a single ds_read_b64 (256 bytes per clock); two neighbouring reads merged into ds_read2_b64 move the same
+// bytes in twice the LDS cycles.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float2 ld9(const float2* q) {
+    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_t;
+    const unsigned long long u = *(lds_u64_t)q;
+    return __builtin_bit_cast(float2, u);
+}
+#else
+inline float2 ld9(const float2* q) { return *q; }
+#endif
+
 // Pair kernel (band2_kernel): sizes shared by the kernel and the host-side plan
 constexpr int kB2R = 3;                 // lags (or FIR outputs) per lane in the exact float64 rounds
 constexpr int kB2Seg = 243;             // lags per exact segment: 81 lanes x 3
@@ -95,7 +108,7 @@ template <bool INV> ECHO_HD void ph9_r9(int tid, const BandParams& p, unsigned c
 #pragma unroll
     for (int m = 0; m < 8; ++m) w[m] = p.f9tw9[m * 512 + tid];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) v[j] = f[pos9(tid + 512 * j)];
+    for (int j = 0; j < 9; ++j) v[j] = ld9(f + pos9(tid + 512 * j));
     if (INV) {
 #pragma unroll
         for (int m = 1; m < 9; ++m) v[m] = cmulc(v[m], w[m - 1]);
@@ -121,7 +134,7 @@ ECHO_HD void ph9_r9_inv_regs(int tid, const BandParams& p, unsigned char* smem, 
 #pragma unroll
     for (int m = 0; m < 8; ++m) w[m] = p.f9tw9[m * 512 + tid];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) v[j] = f[pos9(tid + 512 * j)];
+    for (int j = 0; j < 9; ++j) v[j] = ld9(f + pos9(tid + 512 * j));
 #pragma unroll
     for (int m = 1; m < 9; ++m) v[m] = cmulc(v[m], w[m - 1]);
     dft9<true>(v);
@@ -137,7 +150,7 @@ template <bool INV> ECHO_HD void ph9_r8(int tid, int q, const BandParams& p, uns
     const int i = r % q, base = blk512 * 512 + (r / q) * 8 * q + i;
     float2 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = f[pos9(base + j * q)];
+    for (int j = 0; j < 8; ++j) v[j] = ld9(f + pos9(base + j * q));
     bfly8<INV>(v, tw[i], tw[q + i], tw[2 * q + i]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[pos9(base + j * q)] = v[j];
@@ -149,7 +162,7 @@ ECHO_HD void ph9_mid(int tid, const BandParams& p, unsigned char* smem) {
     float2* f = lds_c(smem, p.off_fft);
     float2 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = f[9 * tid + j];               // pos9(8*tid + j)
+    for (int j = 0; j < 8; ++j) v[j] = ld9(f + 9 * tid + j);         // pos9(8*tid + j)
     dft8<false>(v);
     const float4* bh = reinterpret_cast<const float4*>(p.f9bhat + 8 * tid);
 #pragma unroll

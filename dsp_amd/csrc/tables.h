@@ -1,6 +1,7 @@
 // Host-side construction of the constant tables and the LDS layout of the band kernel.
 // Plain C++ (no HIP): shared by the library's echo_create and by the host emulation used in unit tests.
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -16,7 +17,7 @@ namespace echo {
 struct HostTables {
     std::vector<double> taps_rev;   // [nb][kgroups*kR]
     std::vector<double> chirp;      // [nb][mgroups*kR]
-    std::vector<float2> bw, bhat, tw, post, uk, f9tw9, f9twa, f9twb, f9bhat, f9ghat;
+    std::vector<float2> bw, bhat, tw, post, uk, f9tw9, f9twa, f9twb, f9bhat, f9ghat, taps32x2;
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -152,12 +153,15 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
         p.b2_bwlen = align_up(kB2Seg + 16 + (p.mgroups + 1) * kR, 2);
         (void)kg3; (void)mg3;
         int o = kF9Slots * 8;
-        p.b2_off_ct32 = o; o += align_up((p.kgroups + 1) * kR * 4, 16);
+        p.b2_off_ct32 = o;
         p.b2_off_red = o;  o += 2 * (kF9NT / 64) * 4 * 8;
         p.b2_off_misc = o; o += 16;
         p.b2_smem_bytes = o;
+        p.b2_stagger = 0;
+        if (const char* e = std::getenv("ECHO_DEV_B2_STAGGER")) p.b2_stagger = std::atoi(e);
+        if (const char* e = std::getenv("ECHO_DEV_B2_LDS")) p.b2_smem_bytes = std::max(o, std::atoi(e));   // development probe: occupancy
         p.b2_exact_smem_bytes = 4 * 8 * (p.b2_ywlen + p.b2_bwlen);        // four wavefronts, each with its two windows
-        const bool fits = detector == 0 && p.L <= kF9M && 2 * p.ybuf_len * 4 <= kF9Slots * 8 && N <= kF9NT * kR &&
+        const bool fits = detector == 0 && p.L <= kF9M && p.ybuf_len <= kF9Slots && p.ybuf_len <= 8 * kF9NT && N <= kF9NT * kR &&
                           nn >= 1 && p.half + min_delay + nn <= p.L && nn <= kB2Seg && nn <= 256 &&
                           ceil_div(kB2Seg + M - 1, kB2R) <= 256 && p.b2_exact_smem_bytes <= 64 * 1024;
         p.band2 = fits ? 1 : 0;
@@ -270,6 +274,10 @@ inline void build_tables(HostTables& t, const BandParams& p, const double* taps,
         r8(t.f9twb, 8);
     }
     if (p.band2) {
+        // reversed FIR taps in float32, each stored twice: one 8-byte scalar load is the operand pair of a packed
+        // multiply-add over the two frames of a pair
+        t.taps32x2.resize(t.taps_rev.size());
+        for (size_t i = 0; i < t.taps_rev.size(); ++i) t.taps32x2[i] = mk(t.taps_rev[i], t.taps_rev[i]);
         // matched filter as a cyclic convolution of length 4608 with g[t] = chirp[M-1-t]:
         // (band_sig * g)[k] = sum_j chirp[j] band_sig[k - (M-1) + j] = scipy.signal.correlate(band_sig, chirp, 'full')[k]
         t.f9ghat.resize((size_t)p.nb * kF9M);

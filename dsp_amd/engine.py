@@ -385,9 +385,9 @@ class EchoEngine:
                    _ptr(kalman.init), S, S, C.c_void_p(side.cuda_stream), C.byref(g))
         return ChainGraph(self, g, rx, out, spec, kalman)
 
-    def set_profiling(self, slots: int):
-        """Arm HIP-event timing for the next ``slots`` chain calls (0 disarms)."""
-        self._call("echo_set_profiling", self._h, int(slots))
+    def set_profiling(self, slots: int, every: int = 1):
+        """Arm HIP-event timing for ``slots`` of the next chain calls, every ``every``-th one (0 slots disarms)."""
+        self._call("echo_set_profiling_every", self._h, int(slots), int(every))
 
     def last_kernel_ms(self):
         """Average device time (HIP events on the call's stream) of the stages of the armed chain calls: 'band' is the

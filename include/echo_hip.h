@@ -212,6 +212,17 @@ int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
 
+/* echo_chain / echo_chain_full (full != 0) for callers that keep several batches in flight on several streams (one
+ * handle per stream: a handle's scratch serves one call at a time).  Everything up to the fusion depends on the batch
+ * alone; only the Kalman stage continues the state left by the batch before (ScalarKalman is sequential in time,
+ * airSonar_optimized.py:265-283, :739).  The call makes that stage -- and nothing else -- wait for
+ * kalman_wait_event (a hipEvent_t, or NULL for the first batch) and records kalman_done_event (hipEvent_t or NULL)
+ * behind it, so batches submitted in order on different streams update one Kalman state in that order while their
+ * other kernels overlap.  The Kalman pointers are required.  No counterpart in the reference (its loop is serial). */
+int echo_chain_ordered(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
+                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, int full, void* stream,
+                       void* kalman_wait_event, void* kalman_done_event);
+
 /* One pass of SonarWorker.run()'s loop body with everything it hands on (airSonar_optimized.py:703-757): the records
  * of echo_chain_full (what the log line :741-743, distanceSig :745 and the CSV row :746-747 are made of) plus the
  * waveSig arrays of every frame: spec_db[B][nb][N/2+1] ('band_spectra', :710, :752) and corr[B][nb][N+M-1], the raw
@@ -276,6 +287,10 @@ void echo_graph_destroy(EchoGraph* graph);
  * in milliseconds of the IIR kernel, the band kernel, the spectrum kernel and the fusion(+Kalman) kernels over the armed calls
  * (first internal pass of each call), then re-arms from slot 0.  No counterpart in the reference. */
 int echo_set_profiling(EchoHandle* h, int slots);
+/* As echo_set_profiling, but only every `every`-th chain call is timed (the first one is): the event records between
+ * the kernels keep a call's kernels from following each other back to back, which costs a few per cent of a
+ * pipelined loop's throughput when every call is timed. */
+int echo_set_profiling_every(EchoHandle* h, int slots, int every);
 int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spec_ms, float* fuse_ms);
 /* The same averages as an array, with the band stage split where it runs as two kernels: ms[0..5] = IIR, band stage,
  * spectrum, fusion(+Kalman), pair kernel (float32 matched filter), exact kernel (float64 re-evaluation); the last two

@@ -1,0 +1,71 @@
+"""Several batches in flight (ChainLanes / echo_chain_ordered): records, spectra and the Kalman column must be the
+bytes of the same batches run one after the other on one stream, although only the Kalman stages are ordered."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from dsp_amd import config as C                          # noqa: E402
+from dsp_amd.synth import synth_frames                    # noqa: E402
+
+
+@pytest.mark.parametrize("mode,lanes", [("named", 3), ("named", 2), ("full", 3)])
+def test_lanes_match_sequential_calls(mode, lanes):
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.lanes import ChainLanes
+    cfg = C.optimized_config(C.BANDS_DISTINCT)
+    eng = EchoEngine(cfg)
+    S, nbatch = 16, 7
+    sizes = [S * t for t in (6, 1, 9, 4, 12, 3, 5)]                       # ragged batches, whole time steps each
+    rx = torch.from_numpy(synth_frames(sum(sizes), cfg, eng.tables.tx_pcm, start=31000)).cuda()
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    # one stream, one call after the other
+    kal = BatchedKalman(eng, S)
+    want = [eng.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal, mode=mode) for i in range(nbatch)]
+    want = [(r.clone(), s.clone()) for r, s in want]
+    kx = kal.x.clone()
+    # the same batches on lanes
+    ln = ChainLanes(eng, lanes)
+    kal2 = BatchedKalman(eng, S)
+    outs = [torch.empty((n, 64), dtype=torch.uint8, device="cuda") for n in sizes]
+    specs = [torch.empty((n, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device="cuda") for n in sizes]
+    for i in range(nbatch):
+        ln.submit(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal2, out=outs[i], spec_out=specs[i], mode=mode)
+    ln.join()
+    torch.cuda.synchronize()
+    for i in range(nbatch):
+        assert torch.equal(outs[i], want[i][0]), f"batch {i}: records differ"
+        assert torch.equal(specs[i], want[i][1]), f"batch {i}: spectra differ"
+    assert torch.equal(kal2.x, kx)
+    # without a Kalman state the lanes are plain concurrent chain calls
+    plain, _ = eng.chain(rx[:sizes[0]], want_spectra=False, mode=mode)
+    o = torch.empty((sizes[0], 64), dtype=torch.uint8, device="cuda")
+    ln.submit(rx[:sizes[0]], want_spectra=False, out=o, mode=mode)
+    ln.join(); torch.cuda.synchronize()
+    assert torch.equal(o, plain)
+    ln.close(); eng.close()
+
+
+def test_ordered_call_validates_and_passes_empty_batches_on():
+    import ctypes as Ct
+    from dsp_amd import _lib
+    from dsp_amd.engine import BatchedKalman, EchoEngine, _ptr
+    cfg = C.optimized_config()
+    eng = EchoEngine(cfg)
+    kal = BatchedKalman(eng, 4)
+    s = torch.cuda.current_stream()
+    sp = Ct.c_void_p(s.cuda_stream)
+    rx = torch.zeros((4, cfg.n_rx), dtype=torch.float32, device="cuda")
+    out = torch.empty((4, 64), dtype=torch.uint8, device="cuda")
+    # no Kalman pointers: nothing to order
+    rc = eng.lib.echo_chain_ordered(eng._h, _ptr(rx), _ptr(out), None, None, None, None, 4, 4, 0, sp, None, None)
+    assert rc != 0
+    # an empty batch still records its event, so the chain of batches is not broken
+    ev = torch.cuda.Event(); ev.record(s)
+    rc = eng.lib.echo_chain_ordered(eng._h, _ptr(rx), _ptr(out), None, _ptr(kal.x), _ptr(kal.p), _ptr(kal.init), 0, 4, 0,
+                                    sp, None, Ct.c_void_p(ev.cuda_event))
+    assert rc == 0
+    ev.synchronize()
+    eng.close()

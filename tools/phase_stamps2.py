@@ -22,18 +22,6 @@ assert lib.echo_diag_read_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(nb.value, ns.value)[: min(nb.value, (B + 1) // 2 * 3)].astype(np.int64)
 d = np.diff(st[:, :6], axis=1)
 names = ["tables+y load", "FIR x2", "x write+reduce", "FFT round", "detect+candidates"]
-ex = buf.reshape(nb.value, ns.value)[: min(nb.value, B * 3), 12:17].astype(np.int64)
-de = np.diff(ex, axis=1)
-allst = buf.reshape(nb.value, ns.value).astype(np.int64)
-def span(a, b, rows):
-    x = allst[:rows, a]; y = allst[:rows, b]
-    return int(y.max() - x[x > 0].min()), int((x == 0).sum())
-print("kernel spans in ticks (and unstamped rows): pair", span(0, 5, len(st)), " exact", span(12, 16, min(nb.value, B * 3)))
-sg = buf.reshape(nb.value, ns.value)[: min(nb.value, B * 3)].astype(np.int64)
-print("noise segment: stage, FIR, corr, fold:", np.median(sg[:, 17] - sg[:, 13]), np.median(sg[:, 18] - sg[:, 17]), np.median(sg[:, 19] - sg[:, 18]), np.median(sg[:, 14] - sg[:, 19]))
-print(json.dumps({"exact_total_median": float(np.median(ex[:, 4] - ex[:, 0])), "exact_total_max": float((ex[:, 4] - ex[:, 0]).max()),
-                  "exact_phase_median": dict(zip(["setup", "noise segment", "candidate segments", "median"], map(float, np.median(de, axis=0)))),
-                  "exact_phase_mean": dict(zip(["setup", "noise segment", "candidate segments", "median"], map(float, de.mean(axis=0))))}))
 print(json.dumps({"B": B, "total_median": float(np.median(st[:, 5] - st[:, 0])),
                   "phase_median": dict(zip(names, map(float, np.median(d, axis=0)))),
                   "phase_mean": dict(zip(names, map(float, d.mean(axis=0))))}, indent=1))
