@@ -48,6 +48,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise EchoError(f"{LIB_PATH} not found: build it with `make -C dsp_amd/csrc` "
                         "(or python -c 'import __graft_entry__ as g; g.build()')")
+    # torch first: its libamdhip64 must be the HIP runtime of the process (device memory and streams come from it);
+    # loaded the other way round, the library would bring in the system copy and see no device beside torch's
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     P, I = C.c_void_p, C.c_int
     lib.echo_create.argtypes = [C.POINTER(EchoConfigC), C.POINTER(P)]
