@@ -28,6 +28,8 @@ constexpr int kEnvIterN = 5;           // n <= kEnvIterN * nt: per-thread trip c
                                        // that the global loads of all trips are in flight together
 constexpr int kEnvMaxPeaks = 64;       // find_peaks with distance L // 50 returns at most 51 peaks
 constexpr int kEnvChunk = 64;          // prominence scan: per-chunk max/min
+constexpr int kEnvSuper = 8;           // ... and per group of 8 chunks
+constexpr int kEnvMaxKept = 64;        // peaks the distance rule can keep (L // distance + 1 <= 51), rounded up
 
 struct EnvRes {                        // per (frame, band)
     double snr_db;                     // envelope-path SNR (valid when peak_idx >= 0)
@@ -49,6 +51,7 @@ struct EnvParams {
     int32_t* peaks_out;                // optional [B][nb][kEnvMaxPeaks]: corr_peaks in ascending order, -1 padded
     int off_buf0, off_buf1, off_roots, off_misc, smem_bytes;
     int aux_cmax, aux_cmin, aux_cpos, cand_cap;  // byte offsets inside the auxiliary buffer
+    int aux_smax, aux_smin, aux_kept, aux_side;  // extrema of groups of 8 chunks; kept-peak list; per-side minima
     // Lengths whose half n has a prime factor beyond the mixed-radix passes (e.g. the 4282-sample band signal,
     // n = 2141 prime) take the half-length transforms as Bluestein convolutions of cyclic length bs_m >= 2n - 1 (a
     // length the mixed-radix FFT handles with small radices): `plan` is then the plan of bs_m, not of n.
@@ -63,7 +66,7 @@ struct EnvMisc {
     double ss_sm, ss_x, ss_d;                                          // second statistics pass
     double mean_sm, mean_x, mean_d, std_sm, thr;
     double best_val;
-    int undecided, best_idx, n_final, n_cand;
+    int undecided, best_idx, n_final, n_cand, n_kept, pad_;
 };
 
 constexpr int kEnvBsMaxRadix = 16;     // Bluestein: largest radix of the cyclic length's passes
@@ -87,6 +90,12 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     p.aux_cmin = aux; aux += 5 * nchunk * 8;
     p.cand_cap = L / 2 + 2;                          // strict local maxima are at least two samples apart
     p.aux_cpos = aux; aux += p.cand_cap * 7;         // int pos[cap]; byte state[cap], fk[cap], fu[cap]
+    aux = (aux + 15) & ~15;
+    const int nsuper = (nchunk + kEnvSuper - 1) / kEnvSuper;
+    p.aux_smax = aux; aux += nsuper * 8;
+    p.aux_smin = aux; aux += nsuper * 8;
+    p.aux_side = aux; aux += 2 * kEnvMaxKept * 8;     // double side_min[kept][2]
+    p.aux_kept = aux; aux += kEnvMaxKept * 4;         // int candidate slot of each kept peak
     // each of the two buffers holds the transform (n, or bs_m complex doubles) and, for short signals, at least the
     // reduction scratch and the auxiliary arrays
     int bufbytes = (p.bs_m ? p.bs_m : p.n) * 16;
@@ -172,7 +181,7 @@ ECHO_HD EnvPart1 ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsig
     for (int i = tid; i < p.plan.nroots; i += nt) r[i] = p.roots[i];
     if (tid == 0) {
         EnvMisc* m = env_misc(smem, p);
-        m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0;
+        m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0; m->n_kept = 0;
     }
     return a;
 }
@@ -473,48 +482,111 @@ ECHO_HD void ph_env_distance_update(int tid, int nt, const EnvParams& p, unsigne
         c.fk[t] = 0; c.fu[t] = 0;
     }
 }
-// prominence of each kept peak (scipy _peak_prominences, wlen = None) with chunk-wise skipping (quarter-chunk
-// extrema); peaks below the required prominence (std of the envelope) are dropped
-ECHO_HD double env_side_min(const double* sm, const double* cmax, const double* cmin, int L, int peak, int dir) {
-    constexpr int Q = kEnvChunk / 4;
-    const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
-    const double h = sm[peak];
+// prominence of each kept peak (scipy _peak_prominences, wlen = None).  The scan to one side runs to the first sample
+// above the peak and takes the minimum on the way; it skips whole groups of 8 chunks (512 samples), whole chunks (64)
+// and whole quarter chunks (16) whose maximum does not exceed the peak, taking their minima.  The two sides of every
+// kept peak are scanned by two threads; peaks below the required prominence (std of the envelope) are dropped.
+struct EnvScan { const double *sm, *qmax, *qmin, *cmax, *cmin, *smax, *smin; int L; };
+ECHO_HD EnvScan env_scan(unsigned char* smem, const EnvParams& p, int sm_buf) {
+    unsigned char* a = env_aux(smem, p, sm_buf);
+    const int nchunk = (p.L + kEnvChunk - 1) / kEnvChunk;
+    EnvScan s;
+    s.sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
+    s.qmax = reinterpret_cast<const double*>(a + p.aux_cmax); s.qmin = reinterpret_cast<const double*>(a + p.aux_cmin);
+    s.cmax = s.qmax + 4 * nchunk; s.cmin = s.qmin + 4 * nchunk;
+    s.smax = reinterpret_cast<const double*>(a + p.aux_smax); s.smin = reinterpret_cast<const double*>(a + p.aux_smin);
+    s.L = p.L;
+    return s;
+}
+ECHO_HD double env_side_min(const EnvScan& s, int peak, int dir) {
+    constexpr int Q = kEnvChunk / 4, S = kEnvChunk * kEnvSuper;
+    const int L = s.L;
+    const double h = s.sm[peak];
     double mn = h;
     int i = peak + dir;
     while (i >= 0 && i < L) {
-        // whole chunk (64 samples), then whole quarter chunk (16), at or below the peak: take its minimum and jump
+        const int g = i / S, gb = g * S, ge = gb + S;
+        if (ge <= L && (dir < 0 ? i == ge - 1 : i == gb) && s.smax[g] <= h) {
+            mn = s.smin[g] < mn ? s.smin[g] : mn;
+            i = dir < 0 ? gb - 1 : ge;
+            continue;
+        }
         const int c = i / kEnvChunk, cb = c * kEnvChunk, ce = cb + kEnvChunk;
-        if (ce <= L && (dir < 0 ? i == ce - 1 : i == cb) && cmax[4 * nchunk + c] <= h) {
-            mn = cmin[4 * nchunk + c] < mn ? cmin[4 * nchunk + c] : mn;
+        if (ce <= L && (dir < 0 ? i == ce - 1 : i == cb) && s.cmax[c] <= h) {
+            mn = s.cmin[c] < mn ? s.cmin[c] : mn;
             i = dir < 0 ? cb - 1 : ce;
             continue;
         }
         const int q = i / Q, qb = q * Q, qe = qb + Q;
-        if (qe <= L && (dir < 0 ? i == qe - 1 : i == qb) && cmax[q] <= h) {
-            mn = cmin[q] < mn ? cmin[q] : mn;
+        if (qe <= L && (dir < 0 ? i == qe - 1 : i == qb) && s.qmax[q] <= h) {
+            mn = s.qmin[q] < mn ? s.qmin[q] : mn;
             i = dir < 0 ? qb - 1 : qe;
             continue;
         }
-        if (sm[i] > h) break;
-        mn = sm[i] < mn ? sm[i] : mn;
+        if (s.sm[i] > h) break;
+        mn = s.sm[i] < mn ? s.sm[i] : mn;
         i += dir;
     }
     return mn;
 }
-ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
-    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
-    const double* cmax = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
-    const double* cmin = reinterpret_cast<const double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
+// extrema of the groups of 8 chunks, and the list of the candidates the distance rule kept
+ECHO_HD void ph_env_kept_list(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    unsigned char* a = env_aux(smem, p, sm_buf);
+    const int nchunk = (p.L + kEnvChunk - 1) / kEnvChunk, nsuper = (nchunk + kEnvSuper - 1) / kEnvSuper;
+    const EnvScan s = env_scan(smem, p, sm_buf);
+    double* smax = reinterpret_cast<double*>(a + p.aux_smax);
+    double* smin = reinterpret_cast<double*>(a + p.aux_smin);
+    for (int g = tid; g < nsuper; g += nt) {
+        double mx = -INFINITY, mn = INFINITY;
+        const int c1 = (g + 1) * kEnvSuper < nchunk ? (g + 1) * kEnvSuper : nchunk;
+        for (int c = g * kEnvSuper; c < c1; ++c) { mx = s.cmax[c] > mx ? s.cmax[c] : mx; mn = s.cmin[c] < mn ? s.cmin[c] : mn; }
+        smax[g] = mx; smin[g] = mn;
+    }
     const EnvCand c = env_cand(smem, p, sm_buf);
     EnvMisc* m = env_misc(smem, p);
+    int* kept = reinterpret_cast<int*>(a + p.aux_kept);
     const int nc = m->n_cand;
     for (int t = tid; t < nc; t += nt) {
         if (c.state[t] != 2) continue;
-        const int i = c.pos[t];
-        const double lmin = env_side_min(sm, cmax, cmin, p.L, i, -1);
-        const double rmin = env_side_min(sm, cmax, cmin, p.L, i, +1);
+        const int slot = env_lds_add(&m->n_kept, 1);
+        if (slot < kEnvMaxKept) kept[slot] = t;
+    }
+}
+ECHO_HD void ph_env_side_mins(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    unsigned char* a = env_aux(smem, p, sm_buf);
+    const EnvCand c = env_cand(smem, p, sm_buf);
+    const int nk = env_misc(smem, p)->n_kept;
+    if (nk > kEnvMaxKept) return;                              // cannot happen under the distance rule; handled serially below
+    const int* kept = reinterpret_cast<const int*>(a + p.aux_kept);
+    double* side = reinterpret_cast<double*>(a + p.aux_side);
+    const EnvScan s = env_scan(smem, p, sm_buf);
+    for (int e = tid; e < 2 * nk; e += nt) side[e] = env_side_min(s, c.pos[kept[e >> 1]], (e & 1) ? +1 : -1);
+}
+ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    unsigned char* a = env_aux(smem, p, sm_buf);
+    const EnvCand c = env_cand(smem, p, sm_buf);
+    EnvMisc* m = env_misc(smem, p);
+    const EnvScan s = env_scan(smem, p, sm_buf);
+    const int nk = m->n_kept;
+    if (nk > kEnvMaxKept) {
+        const int nc = m->n_cand;
+        for (int t = tid; t < nc; t += nt) {
+            if (c.state[t] != 2) continue;
+            const int i = c.pos[t];
+            const double lmin = env_side_min(s, i, -1), rmin = env_side_min(s, i, +1);
+            const double base = lmin > rmin ? lmin : rmin;
+            if (!(s.sm[i] - base >= m->std_sm)) c.state[t] = 3;
+            else env_lds_add(&m->n_final, 1);
+        }
+        return;
+    }
+    const int* kept = reinterpret_cast<const int*>(a + p.aux_kept);
+    const double* side = reinterpret_cast<const double*>(a + p.aux_side);
+    for (int k = tid; k < nk; k += nt) {
+        const int t = kept[k];
+        const double lmin = side[2 * k], rmin = side[2 * k + 1];
         const double base = lmin > rmin ? lmin : rmin;
-        if (!(sm[i] - base >= m->std_sm)) c.state[t] = 3;
+        if (!(s.sm[c.pos[t]] - base >= m->std_sm)) c.state[t] = 3;
         else env_lds_add(&m->n_final, 1);
     }
 }
@@ -637,6 +709,8 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
             PHASE(if (tid == 0) env_misc(smem, p)->undecided = 0)                                            \
         }                                                                                                    \
         if ((p).stop_after == 4) break;                                                                      \
+        PHASE(ph_env_kept_list(tid, nt, p, smem, sm_)) SYNC                                                  \
+        PHASE(ph_env_side_mins(tid, nt, p, smem, sm_)) SYNC                                                  \
         PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
         if ((p).stop_after == 5) break;                                                                      \
         PHASE(ph_env_select(tid, nt, p, smem, sm_); ph_env_peaks_out(tid, nt, blk, p, smem, sm_)) SYNC        \
