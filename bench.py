@@ -307,11 +307,11 @@ def main():
         step()
     fence()
     # kernel durations by HIP events on the calls' own streams, inside the timed region.  Event records keep a stream's
-    # kernels from running back to back, so only a sample of the calls is timed: every fourth call of the first lane
+    # kernels from running back to back, so only a sample of the calls is timed: every eighth call of the first lane
     # (every call on a single stream).
     prof_on = os.environ.get("ECHO_BENCH_NOPROF", "0") != "1"
     if prof_on:
-        eng.set_profiling(min(args.steps, 64), every=4 if lanes is not None else 1)
+        eng.set_profiling(min(args.steps, 64), every=8 if lanes is not None else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -405,7 +405,7 @@ def main():
                                  "(~13 MFLOP/frame), so the HBM fraction is low by construction"
                                  + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")
                                  + (f"; {n_lanes} batches are in flight, so this kernel's duration (first lane's calls, "
-                                    "every fourth timed) is stretched by the other lanes' kernels running beside it "
+                                    "every eighth timed) is stretched by the other lanes' kernels running beside it "
                                     "and exceeds ms_per_step: 'unshared' prices the same launch at the duration the "
                                     "kernel has with the GPU to itself" if lanes is not None else "")},
             "kernel_ms": kms,

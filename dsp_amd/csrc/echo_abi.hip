@@ -504,7 +504,7 @@ int echo_set_profiling(EchoHandle* h, int slots) {
     h->prof_used = 0; h->prof_every = 1; h->prof_calls = 0;
     while ((int)h->ev.size() < kEvPerSlot * slots) {
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return ECHO_ERR_HIP;
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return ECHO_ERR_HIP;   // timing only: no cache flush behind a kernel
         h->ev.push_back(e);
     }
     h->prof_slots = slots;
