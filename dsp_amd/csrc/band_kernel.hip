@@ -210,10 +210,6 @@ __global__ __launch_bounds__(kF9NT, 5) void band2_kernel(BandParams p, int B) {
     int* ncand = reinterpret_cast<int*>(smem + p.b2_off_misc);        // [2]
     const int kstart = p.half + p.min_delay;
     if (tid < 2) ncand[tid] = 0;
-    if (p.b2_stagger > 0 && blk < p.b2_stagger) {            // DEV PROBE: de-phase the first round of workgroups
-        const int units = blk & 7;
-        for (int u = 0; u < units; ++u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(45); }
-    }
     // ---- y of both frames, rounded to float32, into LDS: sample n of (frame A, frame B) at ybuf[n + ypad]
     double ymax = 0.0;
     {

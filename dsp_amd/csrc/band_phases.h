@@ -112,7 +112,6 @@ struct BandParams {
     double eps_fir[3];               // per band: bound on the float32 FIR's contribution to a lag's error, per unit max|y|
     double eps_fft[3];               // per band: bound on the float32 transforms' contribution, per unit ||band_sig pair||_2
     int b2_off_ct32, b2_off_red, b2_off_misc, b2_smem_bytes;   // LDS of the pair kernel behind the transform buffer
-    int b2_stagger;                  // DEV PROBE
     int b2_ywlen, b2_bwlen;          // exact kernel: doubles of the y and band_sig windows of one segment
     int b2_exact_smem_bytes;
     struct B2Det* det_out;           // [B][nb] float32 maxima and candidate lags, pair kernel -> exact kernel

@@ -157,9 +157,6 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
         p.b2_off_red = o;  o += 2 * (kF9NT / 64) * 4 * 8;
         p.b2_off_misc = o; o += 16;
         p.b2_smem_bytes = o;
-        p.b2_stagger = 0;
-        if (const char* e = std::getenv("ECHO_DEV_B2_STAGGER")) p.b2_stagger = std::atoi(e);
-        if (const char* e = std::getenv("ECHO_DEV_B2_LDS")) p.b2_smem_bytes = std::max(o, std::atoi(e));   // development probe: occupancy
         p.b2_exact_smem_bytes = 4 * 8 * (p.b2_ywlen + p.b2_bwlen);        // four wavefronts, each with its two windows
         const bool fits = detector == 0 && p.L <= kF9M && p.ybuf_len <= kF9Slots && p.ybuf_len <= 8 * kF9NT && N <= kF9NT * kR &&
                           nn >= 1 && p.half + min_delay + nn <= p.L && nn <= kB2Seg && nn <= 256 &&
