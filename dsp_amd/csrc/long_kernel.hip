@@ -14,7 +14,12 @@ __global__ __launch_bounds__(kLFirNT) void long_fir_kernel(LongParams p) {
     const int tid = threadIdx.x, tile = blockIdx.x, blk = blockIdx.y;
     ph_lfir_load(tid, kLFirNT, tile, blk, p, smem);
     __syncthreads();
-    ph_lfir_run(tid, kLFirNT, tile, blk, p, smem);
+    double acc[kR];
+    ph_lfir_run(tid, kLFirNT, tile, blk, p, smem, acc);
+    __syncthreads();
+    ph_lfir_stage(tid, kLFirNT, smem, acc);
+    __syncthreads();
+    ph_lfir_store(tid, kLFirNT, tile, blk, p, smem);
 }
 
 __global__ __launch_bounds__(kLCorrNT) void long_corr_kernel(LongParams p) {

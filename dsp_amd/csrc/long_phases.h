@@ -172,20 +172,32 @@ ECHO_HD void ph_lfir_load(int tid, int nt, int tile, int blk, const LongParams& 
     for (int i = tid; i < nc; i += nt) ct[i] = p.taps_rev[(size_t)band * nc + i];
 }
 
-ECHO_HD void ph_lfir_run(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem) {
+// The outputs go back through LDS (the input window is dead once every lane has its sums) so that consecutive lanes
+// store consecutive samples: a lane's own nine outputs are 72 bytes apart from its neighbour's.
+ECHO_HD void ph_lfir_run(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem, double (&acc)[kR]) {
     const double* in = reinterpret_cast<const double*>(smem);
     const double* ct = in + nt * kR + (p.kgroups + 1) * kR;
     const int n0 = tile * nt * kR + tid * kR;
-    if (n0 >= p.N) return;
-    double acc[kR];
-    sliding_dot(in + tid * kR, ct, p.kgroups, acc);
+    if (n0 < p.N) sliding_dot(in + tid * kR, ct, p.kgroups, acc);
+    else {
 #pragma unroll
-    for (int r = 0; r < kR; ++r) {
-        const int n = n0 + r;
-        if (n < p.N) {
-            if (p.band_out) p.band_out[(size_t)blk * p.N + n] = acc[r];
-            if (p.bandf_out) p.bandf_out[(size_t)blk * p.N + n] = (float)acc[r];
-        }
+        for (int r = 0; r < kR; ++r) acc[r] = 0.0;
+    }
+}
+ECHO_HD void ph_lfir_stage(int tid, int nt, unsigned char* smem, const double (&acc)[kR]) {
+    double* o = reinterpret_cast<double*>(smem);
+#pragma unroll
+    for (int r = 0; r < kR; ++r) o[tid * kR + r] = acc[r];
+}
+ECHO_HD void ph_lfir_store(int tid, int nt, int tile, int blk, const LongParams& p, unsigned char* smem) {
+    const double* o = reinterpret_cast<const double*>(smem);
+    const int t0 = tile * nt * kR;
+    for (int i = tid; i < nt * kR; i += nt) {
+        const int n = t0 + i;
+        if (n >= p.N) break;
+        const double v = o[i];
+        if (p.band_out) p.band_out[(size_t)blk * p.N + n] = v;
+        if (p.bandf_out) p.bandf_out[(size_t)blk * p.N + n] = (float)v;
     }
 }
 

@@ -103,8 +103,11 @@ extern "C" int emul_long(int N, int M, int K, int nb, int min_delay, int detecto
             const int ftiles = (N + nt * kR - 1) / (nt * kR);
             for (int tile = 0; tile < ftiles; ++tile) {
                 std::memset(s, 0xff, smem.size());
+                std::vector<double> accs((size_t)nt * kR);
                 PHASE(ph_lfir_load(tid, nt, tile, blk, p, s));
-                PHASE(ph_lfir_run(tid, nt, tile, blk, p, s));
+                PHASE(ph_lfir_run(tid, nt, tile, blk, p, s, *reinterpret_cast<double (*)[kR]>(&accs[(size_t)tid * kR])));
+                PHASE(ph_lfir_stage(tid, nt, s, *reinterpret_cast<const double (*)[kR]>(&accs[(size_t)tid * kR])));
+                PHASE(ph_lfir_store(tid, nt, tile, blk, p, s));
             }
             p.band_in = band_out; p.corr_out = corr_out; p.k_begin = k_begin; p.corr_k0 = 0; p.corr_stride = p.L;
             nt = kLCorrNT;
