@@ -69,3 +69,27 @@ def test_ordered_call_validates_and_passes_empty_batches_on():
     assert rc == 0
     ev.synchronize()
     eng.close()
+
+
+def test_lanes_with_batches_of_several_internal_passes():
+    """Batches beyond one internal pass (16384 frames): the Kalman stage of every pass follows the previous batch's."""
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.lanes import ChainLanes
+    cfg = C.optimized_config()
+    eng = EchoEngine(cfg)
+    S = 64
+    sizes = [16384 + 640, 4096, 16384 + 64]
+    rx = eng.synth_frames(sum(sizes), first_frame=5000)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    kal = BatchedKalman(eng, S)
+    want = [eng.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal, want_spectra=False)[0].clone() for i in range(3)]
+    ln = ChainLanes(eng, 2)
+    kal2 = BatchedKalman(eng, S)
+    outs = [torch.empty((n, 64), dtype=torch.uint8, device="cuda") for n in sizes]
+    for i in range(3):
+        ln.submit(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal2, want_spectra=False, out=outs[i])
+    ln.join(); torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], want[i]), f"batch {i}: records differ"
+    assert torch.equal(kal2.x, kal.x)
+    ln.close(); eng.close()
