@@ -246,10 +246,11 @@ struct Df2tQuad {
     double z[NS];
     double bl[NS], al[NS], b0;
     bool last;     // sub-lane 3: there is no state beyond its last one
+    double keep;   // 0 for that sub-lane, 1 for the others
     const double* zi;
     template <int NC> __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) {
         b0 = p.b[band * NC];
-        last = sub == 3;
+        last = sub == 3; keep = last ? 0.0 : 1.0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             bl[j] = p.b[band * NC + NS * sub + j + 1];
@@ -270,11 +271,12 @@ struct Df2tQuad {
         const double yb = b0 * x;
 #pragma unroll
         for (int j = 0; j < NS; ++j) px[j] = x * bl[j];
-        double zn = dpp_quad_next(z[0]);
-        zn = last ? 0.0 : zn;
+        const double zn = dpp_quad_next(z[0]);
         const double yc = z[0] + yb;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) t[j] = ((j + 1 < NS) ? z[j + 1] : zn) + px[j];
+        for (int j = 0; j + 1 < NS; ++j) t[j] = z[j + 1] + px[j];
+        // zn * 1 + px rounds exactly as zn + px; the sub-lane without a next state multiplies by 0 instead of selecting
+        t[NS - 1] = __builtin_fma(zn, keep, px[NS - 1]);
         __builtin_amdgcn_sched_barrier(0);
         const double y = dpp_quad_bcast0(yc);
         double py[NS];
