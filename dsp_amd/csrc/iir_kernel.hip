@@ -230,14 +230,16 @@ __global__ __launch_bounds__(64 * LW) void iir_filtfilt_kernel(IirParams p) {
 // 4x the waves, and at large batches both are bound by the forward-scratch traffic to HBM instead.
 __device__ __forceinline__ double dpp_quad_bcast0(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
+    // mov_dpp: every lane is written, so no previous value of the destination is needed (with update_dpp's `old` operand
+    // the compiler first copies the source into the destination, one more instruction per half)
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, false);          // quad_perm [0,0,0,0]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp_quad_next(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xF9, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xF9, 0xf, 0xf, false);          // quad_perm [1,2,3,3]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xF9, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
