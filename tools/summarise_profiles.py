@@ -55,7 +55,7 @@ json.dump({"units": "bytes per launch; FETCH_SIZE KB x1024 x2 (gfx950 correction
            "kernels": traffic}, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 
-# SQ counters: per kernel and counter the mean per launch, plus the derived figures quoted in DESIGN.md
+# SQ counters: per kernel and counter the mean per launch, plus the derived issue-busy and LDS-busy fractions
 sq = {}
 for sub in ("sq1", "sq2"):
     for k, cs in counter_means(sub).items():
