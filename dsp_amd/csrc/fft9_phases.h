@@ -23,9 +23,14 @@ ECHO_HD int pos9(int e) { return e + (e >> 3); }
 // spectral peak and 0.05 dB near it), the library function on the host.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float echo_log2f(float v) { return __builtin_amdgcn_logf(v); }
+// sqrt(a^2 + b^2) for magnitudes far from overflow and underflow (signals of order 1): the hardware square root
+__device__ __forceinline__ float echo_abs2f(float a, float b) { return __builtin_amdgcn_sqrtf(a * a + b * b); }
 #else
 inline float echo_log2f(float v) { return log2f(v); }
+inline float echo_abs2f(float a, float b) { return hypotf(a, b); }
 #endif
+// 20 log10(max(sqrt(m2), 1e-12)) from the squared magnitude
+ECHO_HD float echo_db_from_sq(float m2) { return 3.01029995663981195f * echo_log2f(fmaxf(m2, 1e-24f)); }
 
 // One complex element from the transform buffer in LDS.  On the device the read is a volatile 8-byte LDS read, which
 // keeps it a single ds_read_b64 (256 bytes per clock); two neighbouring reads merged into ds_read2_b64 move the same
@@ -196,7 +201,7 @@ ECHO_HD void ph9_store(int tid, int nt, int blk, const BandParams& p, unsigned c
         const float2 x = cadd(cmul(ca, mk2(ab.x, ab.y)), cmul(cb, mk2(ab.z, ab.w)));
         // 20 log10(max(|X|, 1e-12)) = 10 log10(max(|X|^2, 1e-24)): no square root on the dB path
         const float m2 = x.x * x.x + x.y * x.y;
-        const float mag = p.spec_db ? 3.01029995663981195f * echo_log2f(fmaxf(m2, 1e-24f)) : sqrtf(m2);
+        const float mag = p.spec_db ? echo_db_from_sq(m2) : sqrtf(m2);
         p.spec_out[(size_t)blk * p.nbins + k] = mag;
     }
 }

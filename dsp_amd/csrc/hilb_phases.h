@@ -51,7 +51,7 @@ template <bool F9> ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const Band
         const float2 zk = cmul(f[hpos<F9>(k)], wk);
         if (k == 0) {
             float m0 = fabsf(zk.x + zk.y), m1 = fabsf(zk.x - zk.y);
-            if (p.spec_db) { m0 = 20.0f * log10f(fmaxf(m0, 1e-12f)); m1 = 20.0f * log10f(fmaxf(m1, 1e-12f)); }
+            if (p.spec_db) { m0 = echo_db_from_sq(m0 * m0); m1 = echo_db_from_sq(m1 * m1); }
             p.spec_out[(size_t)blk * p.nbins] = m0;
             p.spec_out[(size_t)blk * p.nbins + n2] = m1;
             f[hpos<F9>(0)] = mk2(0.f, 0.f);
@@ -67,8 +67,8 @@ template <bool F9> ECHO_HD void ph_hilb_mid(int tid, int nt, int blk, const Band
         const float2 uO = cmul(u, O);
         const float2 Xk = mk2(E.x + uO.x, E.y + uO.y);
         const float2 Xc = mk2(E.x - uO.x, -(E.y - uO.y));
-        float mk_ = sqrtf(Xk.x * Xk.x + Xk.y * Xk.y), mc_ = sqrtf(Xc.x * Xc.x + Xc.y * Xc.y);
-        if (p.spec_db) { mk_ = 20.0f * log10f(fmaxf(mk_, 1e-12f)); mc_ = 20.0f * log10f(fmaxf(mc_, 1e-12f)); }
+        const float sk_ = Xk.x * Xk.x + Xk.y * Xk.y, sc_ = Xc.x * Xc.x + Xc.y * Xc.y;
+        const float mk_ = p.spec_db ? echo_db_from_sq(sk_) : sqrtf(sk_), mc_ = p.spec_db ? echo_db_from_sq(sc_) : sqrtf(sc_);
         p.spec_out[(size_t)blk * p.nbins + k] = mk_;
         if (kc != k) p.spec_out[(size_t)blk * p.nbins + kc] = mc_;
         const float2 Yk = mk2(Xk.y, -Xk.x), Ycc = mk2(Xc.y, Xc.x);           // Y = -i X; conj(Y[n2-k])
@@ -91,8 +91,8 @@ template <bool F9> ECHO_HD void ph_hilb_env(int tid, int nt, int blk, const Band
     for (int m = tid; m < p.n2; m += nt) {
         const float2 d = cmul(f[hpos<F9>(m)], p.bw[m]);
         const float2 xv = x[m];
-        env[2 * m] = hypotf(xv.x, d.x * inv);
-        env[2 * m + 1] = hypotf(xv.y, -d.y * inv);
+        env[2 * m] = echo_abs2f(xv.x, d.x * inv);
+        env[2 * m + 1] = echo_abs2f(xv.y, -d.y * inv);
     }
 }
 
