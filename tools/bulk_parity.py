@@ -2,7 +2,9 @@
 """Larger parity run: the GPU chain against the oracle on many synthetic frames (named and full chain, both band
 sets).  The oracle runs in worker processes on frame shards (they never touch the GPU); the parent runs the GPU chain,
 replays the Kalman filter over the oracle's fused ranges and writes a JSON summary.
-Usage: bulk_parity.py [frames] [workers] [out.json]; exits non-zero on any index or validity mismatch."""
+Usage: bulk_parity.py [frames] [workers] [out.json] [lanes]; exits non-zero on any index or validity mismatch.
+With lanes > 1 the GPU side runs as batches of 4096 frames in flight on that many streams (ChainLanes), which also
+checks that concurrent handles do not disturb each other."""
 import json
 import multiprocessing as mp
 import os
@@ -36,13 +38,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else min(16, os.cpu_count() or 1)
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    n_lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     from dsp_amd import config as C
     from dsp_amd.engine import BatchedKalman, EchoEngine, records_to_numpy
     from dsp_amd.synth import synth_frames
     from oracle import echo_oracle as O
     S = 64
     n -= n % S
-    summary = {"frames_per_leg": n, "first_frame_seed_index": START, "n_streams": S, "oracle_workers": workers, "legs": []}
+    summary = {"lanes": n_lanes, "frames_per_leg": n, "first_frame_seed_index": START, "n_streams": S, "oracle_workers": workers, "legs": []}
     bad = 0
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
@@ -66,7 +69,19 @@ def main():
                 for i in range(n):
                     kf = kfs[i % S]
                     kal[i] = kf.update(o["fused_dist"][i]) if o["valid_any"][i] else (kf.x if kf.x is not None else 0.0)
-                rec, _ = eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), mode=mode, want_spectra=False)
+                if n_lanes > 1:
+                    import torch
+                    from dsp_amd.lanes import ChainLanes
+                    ln = ChainLanes(eng, n_lanes)
+                    rxd = torch.from_numpy(rx).to(eng.device)
+                    rec = torch.empty((n, 64), dtype=torch.uint8, device=eng.device)
+                    kal_l = BatchedKalman(eng, S)
+                    for lo in range(0, n, 4096):
+                        hi = min(n, lo + 4096)
+                        ln.submit(rxd[lo:hi], n_streams=S, kalman=kal_l, want_spectra=False, out=rec[lo:hi], mode=mode)
+                    ln.join(); torch.cuda.synchronize(); ln.close()
+                else:
+                    rec, _ = eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), mode=mode, want_spectra=False)
                 r = records_to_numpy(rec)
                 valid = ((r["valid_mask"][:, None] >> np.arange(3)) & 1).astype(bool)
                 v = o["valid"]
