@@ -57,6 +57,9 @@ def parse():
                          "only their Kalman stages ordered; 1 = one stream, the next step's IIR prefetched beside it")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, nothing overlapped: every step runs its kernels one after the other")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="development aid: no event timing of the kernels at all (the roofline object is then "
+                         "meaningless); shows what the sampled timing costs")
     ap.add_argument("--mode", choices=("named", "full"), default="named",
                     help="'named': the chain the headline metric names (filter + rfft + first_strong_peak + fusion); "
                          "'full': with the reference's Hilbert-envelope branch (secondary measurement)")
@@ -256,8 +259,6 @@ def main():
 
     def gather_one():
         b, st = owed.pop(0)
-        if os.environ.get("ECHO_BENCH_NO_GATHER", "0") == "1":
-            return
         with torch.cuda.stream(st):
             works[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
 
@@ -309,7 +310,7 @@ def main():
     # kernel durations by HIP events on the calls' own streams, inside the timed region.  Event records keep a stream's
     # kernels from running back to back, so only a sample of the calls is timed: every eighth call of the first lane
     # (every call on a single stream).
-    prof_on = os.environ.get("ECHO_BENCH_NOPROF", "0") != "1"
+    prof_on = not args.no_kernel_timing
     if prof_on:
         eng.set_profiling(min(args.steps, 64), every=8 if lanes is not None else 1)
     t0 = time.perf_counter()
