@@ -96,6 +96,13 @@ struct EchoHandle {
     std::vector<char> prof_pair;           // per slot: the band stage ran as pair kernel + exact kernel (event 5 recorded)
     bool capturing = false;                // inside echo_graph_create's stream capture
     int live_graphs = 0;                   // recorded graphs hold pointers into the scratch: it must not move while > 0
+    // Large calls split themselves into chunks that run on three streams of the handle's own (chain_lanes): lane 0 is
+    // the handle itself, lanes 1 and 2 are clones that share its tables and own their scratch.
+    bool is_clone = false;
+    int self_lanes = 1;                    // ECHO_LANES=0: large calls run pass after pass on the caller's stream
+    EchoHandle* lane_clone[2] = {nullptr, nullptr};
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t lane_fork = nullptr, lane_join[3] = {nullptr, nullptr, nullptr}, lane_kal[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -331,6 +338,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->cfg = *cfg;
     if (const char* m = std::getenv("ECHO_IIR_MODE")) h->iir_mode = std::atoi(m);   // development override
     if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
+    if (const char* m = std::getenv("ECHO_LANES")) h->self_lanes = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
     // device address of this GPU's copy of the static scratch array, looked up once per device
@@ -464,6 +472,11 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
 
 void echo_destroy(EchoHandle* h) {
     if (!h) return;
+    for (EchoHandle*& c : h->lane_clone) { if (c) { free_scratch(c); delete c; c = nullptr; } }
+    for (hipStream_t& st : h->lane_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+    if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
+    for (hipEvent_t e : h->lane_join) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->lane_kal) if (e) (void)hipEventDestroy(e);
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
@@ -1026,29 +1039,123 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     return ECHO_OK;
 }
 
+// ---- large calls on three streams of the handle's own.
+// Every kernel of the chain keeps one unit of the GPU busy at a time, and up to the fusion a frame depends on nothing
+// but itself; only the Kalman stage continues what the frames before it left.  A call of at least three chunks
+// (8192 frames each; 4096 on the long-frame path) therefore runs its chunks round-robin on three internal streams --
+// lane 0 with the handle's own scratch, lanes 1 and 2 with clones that share the handle's tables -- forked from and
+// joined to the caller's stream by events, the Kalman stage of each chunk waiting for the previous chunk's.  The
+// records are the bytes of the same call run pass after pass (a frame's results do not depend on its batch).
+constexpr int kLaneChunk = 8192, kLaneChunkLong = 4096, kSelfLanes = 3;
+
+static EchoHandle* clone_for_lane(const EchoHandle* h) {
+    EchoHandle* c = new (std::nothrow) EchoHandle(*h);
+    if (!c) return nullptr;
+    c->is_clone = true;
+    // nothing the clone could free or reuse of the original's: scratch, prefetch state, events, plans, lanes
+    c->sc = Scratch(); c->cap_frames = 0; c->cap_full = 0;
+    c->d_corr = nullptr; c->d_sq = nullptr; c->d_spec = nullptr;
+    c->pf_stream = nullptr; c->pf_t0 = c->pf_t1 = c->pf_rx_ready = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        c->pf_ready[i] = c->pf_consumed[i] = c->chain_end[i] = nullptr;
+        c->pf_consumed_set[i] = c->chain_end_set[i] = false; c->pf_y[i] = nullptr; c->lane_clone[i] = nullptr;
+    }
+    c->pf_fwd = nullptr; c->pf_cap = 0; c->pf_rx = nullptr; c->pf_B = 0; c->pf_valid = false;
+    c->env_plans.clear(); c->d_env_rows = nullptr; c->env_rows_cap = 0;
+    c->prof = false; c->ev.clear(); c->prof_pair.clear(); c->prof_slots = c->prof_used = 0;
+    c->capturing = false; c->live_graphs = 0; c->self_lanes = 0;
+    for (int i = 0; i < 3; ++i) { c->lane_stream[i] = nullptr; c->lane_join[i] = nullptr; c->lane_kal[i] = nullptr; }
+    c->lane_fork = nullptr;
+    return c;
+}
+
+static int ensure_lanes(EchoHandle* h) {
+    if (h->lane_stream[0]) return ECHO_OK;
+    for (int i = 0; i < 2; ++i)
+        if (!h->lane_clone[i] && !(h->lane_clone[i] = clone_for_lane(h))) return ECHO_ERR_NOMEM;
+    if (hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+    for (int i = 0; i < kSelfLanes; ++i)
+        if (hipEventCreateWithFlags(&h->lane_join[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->lane_kal[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+    for (int i = kSelfLanes - 1; i >= 0; --i)              // stream 0 last: it is the mark that everything exists
+        if (hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
+    return ECHO_OK;
+}
+
+// chain_impl, or its chunks on the handle's lanes when the call is large enough
+static int chain_entry(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
+                       uint8_t* kalman_init, int B, int n_streams, void* stream, bool full, double* quality,
+                       double* corr_out, hipEvent_t kal_wait, hipEvent_t kal_done) {
+    const bool kal = kalman_x || kalman_p || kalman_init;
+    int chunk = (h && h->long_path) ? kLaneChunkLong : kLaneChunk;
+    if (h && kal && n_streams >= 1 && n_streams <= chunk) chunk = (chunk / n_streams) * n_streams;
+    const bool lanes = h && on_device(h) && rx && out && h->self_lanes && !h->is_clone && !h->capturing &&
+                       h->live_graphs == 0 && B >= kSelfLanes * chunk &&
+                       (!kal || (kalman_x && kalman_p && kalman_init && n_streams >= 1 && n_streams <= chunk &&
+                                 B % n_streams == 0)) &&
+                       !(full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) &&
+                       detector_supported(h) && !(h->long_path && spec_db && !h->lbase.has_spec);
+    if (!lanes)
+        return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, full, quality,
+                          nullptr, corr_out, kal_wait, kal_done);
+    int rc = ensure_lanes(h);
+    if (rc) return rc;
+    h->pf_valid = false;                                   // a pending single-batch prefetch is discarded
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipEventRecord(h->lane_fork, s) != hipSuccess) return ECHO_ERR_HIP;
+    for (int i = 0; i < kSelfLanes; ++i)
+        if (hipStreamWaitEvent(h->lane_stream[i], h->lane_fork, 0) != hipSuccess) return ECHO_ERR_HIP;
+    const int nb = h->cfg.n_bands, N = h->cfg.n_rx;
+    const size_t nbins = h->long_path ? (size_t)h->lbase.nbins : (size_t)h->base.nbins;
+    const size_t L = (size_t)h->base.L;
+    hipEvent_t prev = kal_wait;
+    int i = 0;
+    for (int f0 = 0; f0 < B; f0 += chunk, ++i) {
+        const int n = std::min(chunk, B - f0), lane = i % kSelfLanes;
+        const bool last = f0 + chunk >= B;
+        EchoHandle* hl = lane == 0 ? h : h->lane_clone[lane - 1];
+        hipEvent_t done = kal ? ((last && kal_done) ? kal_done : h->lane_kal[lane]) : nullptr;
+        rc = chain_impl(hl, rx + (size_t)f0 * N, out + f0, spec_db ? spec_db + (size_t)f0 * nb * nbins : nullptr,
+                        kalman_x, kalman_p, kalman_init, n, n_streams, h->lane_stream[lane], full,
+                        quality ? quality + (size_t)f0 * nb * 2 : nullptr, nullptr,
+                        corr_out ? corr_out + (size_t)f0 * nb * L : nullptr, kal ? prev : nullptr, done);
+        if (rc) break;
+        if (kal) prev = done;
+    }
+    // the caller's stream continues when every lane is through -- also after an error, so that nothing is left behind
+    for (int k = 0; k < kSelfLanes; ++k) {
+        if (hipEventRecord(h->lane_join[k], h->lane_stream[k]) != hipSuccess ||
+            hipStreamWaitEvent(s, h->lane_join[k], 0) != hipSuccess) return ECHO_ERR_HIP;
+    }
+    if (!rc && !kal && kal_done && hipEventRecord(kal_done, s) != hipSuccess) return ECHO_ERR_HIP;
+    return rc;
+}
+
 int echo_chain_ordered(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                        double* kalman_p, uint8_t* kalman_init, int B, int n_streams, int full, void* stream,
                        void* kalman_wait_event, void* kalman_done_event) {
     if (!kalman_x || !kalman_p || !kalman_init) return ECHO_ERR_INVALID;      // without a Kalman stage there is nothing to order
-    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, full != 0, nullptr,
-                      nullptr, nullptr, static_cast<hipEvent_t>(kalman_wait_event),
-                      static_cast<hipEvent_t>(kalman_done_event));
+    return chain_entry(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, full != 0, nullptr,
+                       nullptr, static_cast<hipEvent_t>(kalman_wait_event), static_cast<hipEvent_t>(kalman_done_event));
 }
 
 int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
                uint8_t* kalman_init, int B, int n_streams, void* stream) {
-    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, false, nullptr);
+    return chain_entry(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, false, nullptr,
+                       nullptr, nullptr, nullptr);
 }
 
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality, double* kalman_x,
                     double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
-    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality);
+    return chain_entry(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality,
+                       nullptr, nullptr, nullptr);
 }
 
 int echo_chain_wave(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* corr, double* quality,
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
     if (!spec_db || !corr) return ECHO_ERR_INVALID;
-    return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality, nullptr, corr);
+    return chain_entry(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, true, quality, corr,
+                       nullptr, nullptr);
 }
 
 int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,

@@ -412,26 +412,38 @@ def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
 
 
 def test_many_pass_call_pipelines_itself_identically(eng_default, monkeypatch):
-    """A call of eight or more internal passes runs the IIR of pass k+1 on the handle's own stream beside the band
-    kernel of pass k (8192-frame passes); records, spectra and Kalman states must be byte-identical to the same call
-    with the in-line IIR (ECHO_INNER_PIPELINE=0, read at handle creation), ragged last pass included, twice in a row."""
+    """Large calls split themselves: by default into 8192-frame chunks on three streams of the handle's own (only the
+    Kalman stages in order); with ECHO_LANES=0 into 8192-frame passes on the caller's stream with the IIR of pass k+1
+    on a second stream beside the band kernel of pass k.  Records, spectra and Kalman states of both must be
+    byte-identical to the same call run pass after pass with in-line IIRs (ECHO_LANES=0, ECHO_INNER_PIPELINE=0; the
+    switches are read at handle creation), ragged last chunk included, twice in a row; likewise the full chain."""
     from dsp_amd.engine import BatchedKalman
     cfg = eng_default.cfg
     B, S = 8 * 8192 + 4464, 16
     pool = torch.from_numpy(synth_frames(2048, cfg, eng_default.tables.tx_pcm)).to(eng_default.device)
     rx = pool.repeat((B + 2047) // 2048, 1)[:B].roll(3, dims=0).contiguous()
+    monkeypatch.setenv("ECHO_LANES", "0")
+    piped = _engine(cfg)
     monkeypatch.setenv("ECHO_INNER_PIPELINE", "0")
     plain = _engine(cfg)
     monkeypatch.delenv("ECHO_INNER_PIPELINE")
-    k_plain, k_pipe = BatchedKalman(plain, S), BatchedKalman(eng_default, S)
+    monkeypatch.delenv("ECHO_LANES")
+    k_plain, k_pipe, k_lanes = BatchedKalman(plain, S), BatchedKalman(piped, S), BatchedKalman(eng_default, S)
     for _ in range(2):
         want, want_spec = plain.chain(rx, n_streams=S, kalman=k_plain, want_spectra=True)
-        got, got_spec = eng_default.chain(rx, n_streams=S, kalman=k_pipe, want_spectra=True)
-        torch.cuda.synchronize()
-        assert torch.equal(got, want)
-        assert torch.equal(got_spec, want_spec)
-        assert torch.equal(k_plain.x, k_pipe.x) and torch.equal(k_plain.p, k_pipe.p)
-    plain.close()
+        for eng, k in ((piped, k_pipe), (eng_default, k_lanes)):
+            got, got_spec = eng.chain(rx, n_streams=S, kalman=k, want_spectra=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+            assert torch.equal(got_spec, want_spec)
+            assert torch.equal(k_plain.x, k.x) and torch.equal(k_plain.p, k.p)
+    # the full chain, without a Kalman state, on a batch of just three chunks plus a ragged one
+    n = 3 * 8192 + 100
+    want, _ = plain.chain(rx[:n], mode="full", want_spectra=False)
+    got, _ = eng_default.chain(rx[:n], mode="full", want_spectra=False)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    plain.close(); piped.close()
 
 
 def test_chain_one_million_frames_periodic_input(eng_default):
