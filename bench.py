@@ -210,23 +210,19 @@ def main():
                 rx = rx.repeat((B + 4095) // 4096, 1)[:B].contiguous()
     # Batches in flight.  Up to the fusion a batch depends on nothing but its frames, and every kernel of the chain
     # keeps one unit of the GPU busy at a time, so consecutive steps run on `lanes` streams (ChainLanes: one library
-    # handle each) with only their Kalman stages ordered.  The sharded job submits its shard in chunks the same way.
+    # handle each) with only their Kalman stages ordered.
     # With one lane the step runs on one stream and only the next step's IIR is started beside it (chain_prefetch).
-    n_lanes = 1 if args.no_pipeline else max(1, args.lanes)
-    CHUNK = 8192
-    if strong and n_lanes > 1:
-        chunks = [(c, min(c + CHUNK, B)) for c in range(0, B, CHUNK)]
-        import math
-        S = _largest_divisor(math.gcd(B, CHUNK) if B > CHUNK else B, N_STREAMS)
-    else:
-        chunks = [(0, B)]
-        S = _largest_divisor(B, N_STREAMS)                  # 64 whenever the batch is a multiple of it
+    # The sharded job is one chain call per step over the whole shard: the library splits a call of that size into
+    # chunks on three streams of its own.
+    n_lanes = 1 if (args.no_pipeline or strong) else max(1, args.lanes)
+    CHUNK = 8192                                            # the library's chunk for large calls
+    S = _largest_divisor(B, N_STREAMS)                      # 64 whenever the batch is a multiple of it
     kal = BatchedKalman(eng, S)
     lanes = ChainLanes(eng, n_lanes) if n_lanes > 1 else None
     if lanes is not None:
-        lanes.reserve(min(B, CHUNK) if strong else B)
+        lanes.reserve(B)
     else:
-        eng.reserve(B)
+        eng.reserve(min(B, 16384))
     if lanes is not None:
         # the lanes' streams take their hardware queues first (one untimed batch each), the collective library's
         # streams after them: created the other way round, lanes ended up sharing a queue and ran one after the other
@@ -269,21 +265,15 @@ def main():
             works[buf].wait()
         spec = specs[buf % nspec]
         if lanes is not None:
-            for lo_, hi_ in chunks:
-                ev = lanes.submit(rx[lo_:hi_], n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf][lo_:hi_],
-                                  spec_out=spec[lo_:hi_] if want_spec else None, mode=args.mode)
+            lanes.submit(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
             if use_dist:
-                if strong:
-                    lanes.join()                        # a step of the sharded job ends with the gather of the whole shard
-                    works[buf] = dist.all_gather_into_tensor(gathered[buf], send[buf], async_op=True)
-                else:
-                    # The gather of a batch is issued from the batch's own lane, n_lanes - 1 steps later (the rest at
-                    # the fence): by then every lane's newer work is queued behind work that cannot start before this
-                    # batch is done anyway, so the collective's wait for the batch -- its stream shares one of the few
-                    # hardware queues with some lane -- holds nothing back.
-                    owed.append((buf, lanes.last_stream))
-                    if len(owed) >= n_lanes:
-                        gather_one()
+                # The gather of a batch is issued from the batch's own lane, n_lanes - 1 steps later (the rest at the
+                # fence): by then every lane's newer work is queued behind work that cannot start before this batch is
+                # done anyway, so the collective's wait for the batch -- its stream shares one of the few hardware
+                # queues with some lane -- holds nothing back.
+                owed.append((buf, lanes.last_stream))
+                if len(owed) >= n_lanes:
+                    gather_one()
             return
         eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
         if pipeline:
@@ -350,8 +340,8 @@ def main():
         # the first pass of each call
         if args.workload in ("original", "twopeak"):
             launch_frames = min(B, 4096)
-        elif lanes is not None and strong:
-            launch_frames = min(B, CHUNK)
+        elif B >= 3 * CHUNK and os.environ.get("ECHO_LANES", "1") != "0":
+            launch_frames = CHUNK                           # large calls: chunks on the library's own streams
         else:
             launch_frames = 8192 if B >= 65536 and os.environ.get("ECHO_INNER_PIPELINE", "1") != "0" else min(B, 16384)
         # the dominant kernel: the longest of the chain's kernels by its event-measured duration in this run (the
@@ -395,7 +385,9 @@ def main():
                                    f"{S} streams" + (", RCCL all-gather of 64-B result records" if use_dist else "")
                                    + (", IIR of the next step prefetched on a second stream" if pipeline else "")
                                    + (f", {n_lanes} batches in flight on {n_lanes} streams (Kalman stages in order)"
-                                      if lanes is not None else ""),
+                                      if lanes is not None else "")
+                                   + (", one chain call per step (the library runs its chunks of 8192 frames on three "
+                                      "streams of its own)" if strong else ""),
                        "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode,
                        "pipelined_iir": pipeline, "lanes": n_lanes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
