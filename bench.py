@@ -215,7 +215,7 @@ def main():
     # The sharded job is one chain call per step over the whole shard: the library splits a call of that size into
     # chunks on three streams of its own.
     n_lanes = 1 if (args.no_pipeline or strong) else max(1, args.lanes)
-    CHUNK = 8192                                            # the library's chunk for large calls
+    CHUNK = 4096                                            # the library's chunk for large calls
     S = _largest_divisor(B, N_STREAMS)                      # 64 whenever the batch is a multiple of it
     kal = BatchedKalman(eng, S)
     lanes = ChainLanes(eng, n_lanes) if n_lanes > 1 else None
@@ -386,7 +386,7 @@ def main():
                                    + (", IIR of the next step prefetched on a second stream" if pipeline else "")
                                    + (f", {n_lanes} batches in flight on {n_lanes} streams (Kalman stages in order)"
                                       if lanes is not None else "")
-                                   + (", one chain call per step (the library runs its chunks of 8192 frames on three "
+                                   + (", one chain call per step (the library runs its chunks of 4096 frames on three "
                                       "streams of its own)" if strong else ""),
                        "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode,
                        "pipelined_iir": pipeline, "lanes": n_lanes},

@@ -1042,11 +1042,12 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
 // ---- large calls on three streams of the handle's own.
 // Every kernel of the chain keeps one unit of the GPU busy at a time, and up to the fusion a frame depends on nothing
 // but itself; only the Kalman stage continues what the frames before it left.  A call of at least three chunks
-// (8192 frames each; 4096 on the long-frame path) therefore runs its chunks round-robin on three internal streams --
+// (4096 frames each: chunks of 8192 were slower at every call size from 12288 to 65536 frames, chunks of 2048 too)
+// therefore runs its chunks round-robin on three internal streams --
 // lane 0 with the handle's own scratch, lanes 1 and 2 with clones that share the handle's tables -- forked from and
 // joined to the caller's stream by events, the Kalman stage of each chunk waiting for the previous chunk's.  The
 // records are the bytes of the same call run pass after pass (a frame's results do not depend on its batch).
-constexpr int kLaneChunk = 8192, kLaneChunkLong = 4096, kSelfLanes = 3;
+constexpr int kLaneChunk = 4096, kLaneChunkLong = 4096, kSelfLanes = 3;
 
 static EchoHandle* clone_for_lane(const EchoHandle* h) {
     EchoHandle* c = new (std::nothrow) EchoHandle(*h);

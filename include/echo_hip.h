@@ -198,7 +198,7 @@ int echo_kalman_update(EchoHandle* h, double* x, double* p, uint8_t* init, const
  * (frame i = stream i % n_streams at time i / n_streams): bandpass -> {rfft dB spectrum, correlate ->
  * first_strong_peak -> confidence} -> fusion -> Kalman (airSonar_optimized.py:629-676, :703-747, envelope
  * stages excluded).  spec_db may be NULL (no spectra stored); kalman_* may be NULL (record.kalman = fused).
- * Large calls (from 24576 frames; 12288 on the long-frame path) split themselves into chunks that run on three streams
+ * Large calls (from 12288 frames) split themselves into chunks of 4096 frames that run on three streams
  * of the handle's own, forked from and joined to `stream` by events, with only the Kalman stages of the chunks in
  * order: the results are the bytes of the same call run pass after pass, the caller sees one call on one stream.
  * (ECHO_LANES=0 in the environment at echo_create keeps such calls on the caller's stream.)  The same holds for

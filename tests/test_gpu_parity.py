@@ -412,7 +412,7 @@ def test_streaming_graph_replay_matches_direct_calls(gold_realtime):
 
 
 def test_many_pass_call_pipelines_itself_identically(eng_default, monkeypatch):
-    """Large calls split themselves: by default into 8192-frame chunks on three streams of the handle's own (only the
+    """Large calls split themselves: by default into 4096-frame chunks on three streams of the handle's own (only the
     Kalman stages in order); with ECHO_LANES=0 into 8192-frame passes on the caller's stream with the IIR of pass k+1
     on a second stream beside the band kernel of pass k.  Records, spectra and Kalman states of both must be
     byte-identical to the same call run pass after pass with in-line IIRs (ECHO_LANES=0, ECHO_INNER_PIPELINE=0; the
@@ -438,7 +438,7 @@ def test_many_pass_call_pipelines_itself_identically(eng_default, monkeypatch):
             assert torch.equal(got_spec, want_spec)
             assert torch.equal(k_plain.x, k.x) and torch.equal(k_plain.p, k.p)
     # the full chain, without a Kalman state, on a batch of just three chunks plus a ragged one
-    n = 3 * 8192 + 100
+    n = 3 * 4096 + 100
     want, _ = plain.chain(rx[:n], mode="full", want_spectra=False)
     got, _ = eng_default.chain(rx[:n], mode="full", want_spectra=False)
     torch.cuda.synchronize()
