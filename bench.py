@@ -265,7 +265,10 @@ def main():
             works[buf].wait()
         spec = specs[buf % nspec]
         if lanes is not None:
-            lanes.submit(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
+            # rx is resident and never rewritten; the buffers of this slot are free once works[buf] has been waited for,
+            # which the lane has to see only when there is a collective
+            lanes.submit(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode,
+                         inputs_ready=not use_dist)
             if use_dist:
                 # The gather of a batch is issued from the batch's own lane, n_lanes - 1 steps later (the rest at the
                 # fence): by then every lane's newer work is queued behind work that cannot start before this batch is

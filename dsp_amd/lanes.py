@@ -35,6 +35,12 @@ class ChainLanes:
             # default priority on purpose: with high-priority lanes a collective queued at normal priority behind
             # them never got to run on this driver (the lanes' wait packets kept the high-priority queues active)
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)]
+            # one event per lane for the order of the Kalman stages, recorded once here so that it exists: a lane's
+            # event is recorded again by every ordered call on that lane, and the next batch's wait is queued before
+            # the lane's following call records it once more
+            self._kal_ev = [torch.cuda.Event() for _ in range(lanes)]
+            for e, st in zip(self._kal_ev, self.streams):
+                e.record(st)
         self._next = 0
         self.last_stream: Optional[torch.cuda.Stream] = None    # the lane of the batch submitted last
         self._kal_done: Optional[torch.cuda.Event] = None      # Kalman stage of the batch submitted last
@@ -45,11 +51,14 @@ class ChainLanes:
 
     def submit(self, rx: torch.Tensor, n_streams: Optional[int] = None, kalman: Optional[BatchedKalman] = None,
                want_spectra: bool = True, out: Optional[torch.Tensor] = None, spec_out: Optional[torch.Tensor] = None,
-               mode: str = "named") -> torch.cuda.Event:
+               mode: str = "named", inputs_ready: bool = False, want_event: bool = False) -> Optional[torch.cuda.Event]:
         """Queue one batch on the next lane.  Arguments as ``EchoEngine.chain``; ``out`` (uint8 [B,64]) is required, and
-        ``spec_out`` when ``want_spectra``.  Returns the event that completes with the batch."""
-        eng = self.engines[self._next]
-        stream = self.streams[self._next]
+        ``spec_out`` when ``want_spectra``.  ``inputs_ready``: ``rx`` is complete already (nothing pending on the
+        caller's stream produces it), so the lane need not wait for that stream.  Returns the event that completes with
+        the batch when ``want_event``; ``last_stream`` is the lane the batch went to."""
+        lane = self._next
+        eng = self.engines[lane]
+        stream = self.streams[lane]
         self.last_stream = stream
         self._next = (self._next + 1) % len(self.engines)
         cfg = eng.cfg
@@ -65,9 +74,9 @@ class ChainLanes:
         S = n_streams if n_streams is not None else (kalman.S if kalman is not None else max(B, 1))
         if kalman is not None and (kalman.S != S or kalman.engine.device != self.device):
             raise _lib.EchoError("kalman state must hold n_streams streams on the engine's device")
-        cur = torch.cuda.current_stream(self.device)
-        stream.wait_stream(cur)                                 # the inputs are ready once the caller's stream gets here
-        done = torch.cuda.Event()
+        if not inputs_ready:
+            stream.wait_stream(torch.cuda.current_stream(self.device))   # the inputs are ready once that stream gets here
+        done = None
         with torch.cuda.device(self.device), torch.cuda.stream(stream):
             sp = C.c_void_p(stream.cuda_stream)
             spec = spec_out if want_spectra else None
@@ -77,15 +86,16 @@ class ChainLanes:
                        (None, None, None, B, S, sp)
                 _lib.check(getattr(eng.lib, name)(*args), name)
             else:
-                kdone = torch.cuda.Event()
-                kdone.record(stream)                            # creates the underlying event; recorded again by the call
+                kdone = self._kal_ev[lane]
                 wait = self._kal_done
                 _lib.check(eng.lib.echo_chain_ordered(
                     eng._h, _ptr(rx), _ptr(out), _ptr(spec), _ptr(kalman.x), _ptr(kalman.p), _ptr(kalman.init), B, S,
                     1 if mode == "full" else 0, sp, C.c_void_p(wait.cuda_event) if wait is not None else None,
                     C.c_void_p(kdone.cuda_event)), "echo_chain_ordered")
                 self._kal_done = kdone
-            done.record(stream)
+            if want_event:
+                done = torch.cuda.Event()
+                done.record(stream)
         return done
 
     def join(self):
