@@ -1,3 +1,5 @@
+"""Development probe: throughput of single echo_chain calls of growing size (synchronised after each call), with the
+library's own three-stream split for large calls on or off (ECHO_LANES=0)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsp_amd.config import optimized_config
