@@ -18,9 +18,39 @@ __global__ __launch_bounds__(kCfNT) void long_corr_fft_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
+// The same transform followed by first_strong_peak of the original parameter set (airSonar.py:104-117) on the lags
+// it has just produced: the correlation never leaves LDS.
+__global__ __launch_bounds__(kCfNT) void long_corr_det_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_CF_DET_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kCfNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
 int cfft_kernel_prepare() {
+    static_assert(kCfDetSmem <= 160 * 1024, "transform and detector scratch exceed the LDS of a compute unit");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_det_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kCfDetSmem) != hipSuccess) return ECHO_ERR_HIP;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_fft_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kCfSmem) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
+}
+
+// true when launch_long_corr_det can replace launch_long_corr + launch_long_detect for these parameters
+bool long_corr_det_fits(const LongParams& p) {
+    return p.cf_use && p.cf_g && p.cf_w2 && p.cf_tw && p.detector == ECHO_DET_MAD && p.L - p.half > p.min_delay &&
+           p.k_begin == p.half + p.min_delay && cf_pairs(p) == 1;
+}
+
+int launch_long_corr_det(const LongParams& q, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    LongParams p = q;
+    if (!long_corr_det_fits(p) || !p.res_out) return ECHO_ERR_INVALID;
+    p.det_view = 1; p.det_q0 = p.k_begin - p.half; p.det_lds_off = kCfSmem;
+    hipLaunchKernelGGL(long_corr_det_kernel, dim3(B * p.nb), dim3(kCfNT), kCfDetSmem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
 }
 
 int launch_long_corr_fft(const LongParams& p, int B, hipStream_t s) {

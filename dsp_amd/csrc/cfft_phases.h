@@ -21,6 +21,7 @@ constexpr int kCfF = 8192;                       // cyclic length (complex point
 constexpr int kCfNT = 1024;                      // threads per workgroup: one radix-8 butterfly each
 constexpr int kCfSlots = kCfF + kCfF / 8;        // padded LDS slots
 constexpr int kCfSmem = kCfSlots * 16;
+constexpr int kCfDetSmem = kCfSmem + kDetExtra;   // with the detector's histograms and scalars behind the transform
 constexpr int kCfTwLen = 3 * (512 + 64 + 8);     // pass twiddles: per stride q the runs W^i, W^2i, W^4i (i < q), W = exp(-2 pi i/(8q))
 
 typedef cpx<double> zd;
@@ -148,6 +149,35 @@ ECHO_HD void ph_cf_store(int tid, int nt, int pair, int blk, const LongParams& p
         }
     }
 }
+
+// The last inverse stage in place, for a detector that continues in the same workgroup: slot zpos(i) then holds lag i
+// of the first sub-block in its real part and of the second in its imaginary part (LongParams::det_view == 1).  Every
+// thread rewrites the two slots it read.  Also clears the detector's scalars.
+ECHO_HD void ph_cf_finish_inplace(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    zd* f = reinterpret_cast<zd*>(smem);
+    for (int i = tid; i < kCfF / 2; i += nt) {
+        const zd A = f[zpos(i)], Bw = zmulc(f[zpos(i + kCfF / 2)], p.cf_w2[i]);
+        f[zpos(i)] = zadd(A, Bw);
+        f[zpos(i + kCfF / 2)] = zsub(A, Bw);
+    }
+    if (tid == 0) det_misc_init(det_misc(p, smem));
+}
+
+#define ECHO_CF_TRANSFORM(PHASE, SYNC, p, smem, pair, blk, nt)                     \
+    PHASE(ph_cf_load(tid, nt, pair, blk, p, smem)) SYNC                             \
+    PHASE(ph_cf_r8<false>(tid, nt, 512, p, smem)) SYNC                              \
+    PHASE(ph_cf_r8<false>(tid, nt, 64, p, smem)) SYNC                               \
+    PHASE(ph_cf_r8<false>(tid, nt, 8, p, smem)) SYNC                                \
+    PHASE(ph_cf_mid(tid, nt, blk, p, smem)) SYNC                                    \
+    PHASE(ph_cf_r8<true>(tid, nt, 8, p, smem)) SYNC                                 \
+    PHASE(ph_cf_r8<true>(tid, nt, 64, p, smem)) SYNC                                \
+    PHASE(ph_cf_r8<true>(tid, nt, 512, p, smem)) SYNC
+
+// matched filter and the median/MAD detector in one workgroup: the lags [k_begin, L) must fit one pair of sub-blocks
+#define ECHO_CF_DET_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                         \
+    ECHO_CF_TRANSFORM(PHASE, SYNC, p, smem, 0, blk, nt)                             \
+    PHASE(ph_cf_finish_inplace(tid, nt, p, smem)) SYNC                              \
+    ECHO_LDET_BODY(PHASE, SYNC, p, smem, blk, nt)
 
 #define ECHO_CF_SEQUENCE(PHASE, SYNC, p, smem, pair, blk, nt)                      \
     PHASE(ph_cf_load(tid, nt, pair, blk, p, smem)) SYNC                             \

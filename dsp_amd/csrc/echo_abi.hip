@@ -99,6 +99,7 @@ struct EchoHandle {
     // Large calls split themselves into chunks that run on three streams of the handle's own (chain_lanes): lane 0 is
     // the handle itself, lanes 1 and 2 are clones that share its tables and own their scratch.
     bool is_clone = false;
+    int fuse_det = 1;                      // ECHO_FUSE_DET=0: matched filter and median/MAD detector of long frames as two kernels
     int self_lanes = 1;                    // ECHO_LANES=0: large calls run pass after pass on the caller's stream
     EchoHandle* lane_clone[2] = {nullptr, nullptr};
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
@@ -339,6 +340,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (const char* m = std::getenv("ECHO_IIR_MODE")) h->iir_mode = std::atoi(m);   // development override
     if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
     if (const char* m = std::getenv("ECHO_LANES")) h->self_lanes = std::atoi(m);
+    if (const char* m = std::getenv("ECHO_FUSE_DET")) h->fuse_det = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
     // device address of this GPU's copy of the static scratch array, looked up once per device
@@ -950,10 +952,14 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             const bool all_lags = q.detector != ECHO_DET_MAD;           // every other detector reports max|corr| over all lags
             q.k_begin = all_lags ? 0 : std::min(q.half + q.min_delay, q.L - 1);
             q.corr_k0 = all_lags ? 0 : q.half; q.corr_stride = all_lags ? q.L : q.L - q.half;
-            rc = launch_long_corr(q, n, s);
-            if (rc) return rc;
             q.det_io = sc.pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = sc.res;
-            rc = launch_long_detect(q, n, s);
+            if (h->fuse_det && long_corr_det_fits(q)) {
+                rc = launch_long_corr_det(q, n, s);         // the correlation stays in the workgroup that detects on it
+            } else {
+                rc = launch_long_corr(q, n, s);
+                if (rc) return rc;
+                rc = launch_long_detect(q, n, s);
+            }
             if (rc) return rc;
             if (spec_db) {
                 q.spec_db = 1; q.spec_in = sc.band; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;

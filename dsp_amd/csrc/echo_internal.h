@@ -59,6 +59,8 @@ int launch_long_fir(const LongParams& p, int B, hipStream_t s);        // B*nb <
 int launch_long_corr(const LongParams& p, int B, hipStream_t s);         // direct sum, or the FFT form when p.cf_use
 int cfft_kernel_prepare();
 int launch_long_corr_fft(const LongParams& p, int B, hipStream_t s);
+bool long_corr_det_fits(const LongParams& p);
+int launch_long_corr_det(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
 int launch_long_spec(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);

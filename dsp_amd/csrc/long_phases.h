@@ -35,7 +35,20 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, bool active)
 #define ECHO_WAVE_COUNT_ADD(counter, flag)                                                    \
     do { const unsigned long long b_ = __ballot(flag);                                        \
          if (b_ && __lane_id() == 0) atomicAdd((counter), (int)__popcll(b_)); } while (0)
+#define ECHO_LDS_FETCH_ADD(p, v) atomicAdd((p), (v))
+// *counter += sum of v over the wavefront / *ptr = max(*ptr, v over the wavefront) (all lanes must call): one atomic each
+#define ECHO_WAVE_SUM_ADD(counter, v)                                                         \
+    do { int s_ = (v);                                                                        \
+         for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_);                        \
+         if (s_ && __lane_id() == 0) atomicAdd((counter), s_); } while (0)
+#define ECHO_WAVE_MAX_U64(ptr, v)                                                             \
+    do { unsigned long long s_ = (v);                                                         \
+         for (int o_ = 32; o_ > 0; o_ >>= 1) { const unsigned long long t_ = __shfl_xor(s_, o_); s_ = t_ > s_ ? t_ : s_; } \
+         if (s_ && __lane_id() == 0) atomicMax((ptr), s_); } while (0)
 #else
+#define ECHO_LDS_FETCH_ADD(p, v) ((*(p) += (v)) - (v))
+#define ECHO_WAVE_SUM_ADD(counter, v) (*(counter) += (v))
+#define ECHO_WAVE_MAX_U64(ptr, v) do { if ((v) > *(ptr)) *(ptr) = (v); } while (0)
 #define ECHO_LDS_ADD(p, v) (*(p) += (v))
 #define ECHO_LDS_MIN(p, v) (*(p) = (v) < *(p) ? (v) : *(p))
 #define ECHO_HIST_ADD(hist, digit, active) do { if (active) (hist)[(digit)] += 1; } while (0)
@@ -76,6 +89,11 @@ struct LongParams {
     double* det_io;
     long long det_stride;
     int det_off, write_mutated;
+    // where the detector finds pos in LDS.  det_view 0: double pos[npos] at the start.  det_view 1: the matched
+    // filter's transform, finished in place (cfft_phases.h), holds it: pos[q] for q >= det_q0 is component w of complex
+    // slot i + i/8, with q - det_q0 = w * cf_V + i; below det_q0 lies the blind zone (zero).  det_lds_off: byte offset
+    // of the histograms and scalars behind pos.
+    int det_view, det_q0, det_lds_off;
     BandRes* res_out;                // [B][nb]
     // spectrum: rfft of the N-sample band signal as a packed complex FFT of length N/2 (gfft.h), float32
     int has_spec, n2, nbins, spec_db;
@@ -97,7 +115,16 @@ struct DetMisc {                     // detector scalars in LDS
     double med, mad, lo, hi;
     int rank, shift, first, cnt;     // cnt: elements left in the chosen bin
     int nzero, pad;                  // nzero: elements equal to +0.0 (counted in the first pass)
+    // the shortcut (ph_fs_*): statistics of pos beyond the blind zone, and the state of the selection by one histogram
+    unsigned long long amax_bits;    // bit image of max |pos|
+    int n_neg, n_zero, n_nan;        // negative, zero and NaN elements
+    int fast;                        // 1: the shortcut's assumptions hold so far; 2: pos is all zero; 0: take the general path
+    int bin, below, nlist, base;     // chosen bin, elements in lower bins, collected elements, (key >> kFsShift) of bin 0
+    int pad2[2];
 };
+constexpr int kFsBins = 2048, kFsShift = 45, kFsList = 64;   // bins of 1/128 octave: 16 octaves below the maximum
+constexpr int kDetExtra = 2 * 256 * 4 + 112 + kFsBins * 4 + 32 * 4 + kFsList * 8;   // detector LDS behind pos
+static_assert(sizeof(DetMisc) <= 112, "DetMisc outgrew its LDS slot");
 
 inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay, int detector) {
     p.N = N; p.M = M; p.L = N + M - 1; p.half = p.L / 2; p.nb = nb; p.K = K;
@@ -111,7 +138,8 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.cf_use = (M >= 512 && M <= 6144) ? 1 : 0;
     p.cf_V = 8192 - M + 1;
     const int npos = p.L - p.half;
-    p.det_smem = ((npos + 1) & ~1) * 8 + 2 * 256 * 4 + (int)sizeof(DetMisc);
+    p.det_view = 0; p.det_q0 = 0; p.det_lds_off = ((npos + 1) & ~1) * 8;
+    p.det_smem = p.det_lds_off + kDetExtra;
     p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;
     p.lm_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + kLDetNT * 4 + 64;
     p.n2 = N / 2; p.nbins = N / 2 + 1;
@@ -257,10 +285,29 @@ ECHO_HD double key_value(unsigned long long k) {
 
 ECHO_HD double* det_pos(unsigned char* smem) { return reinterpret_cast<double*>(smem); }
 ECHO_HD int* det_hist(const LongParams& p, unsigned char* smem) {
-    return reinterpret_cast<int*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
+    return reinterpret_cast<int*>(smem + p.det_lds_off);
+}
+// pos[q] of this workgroup's (frame, band)
+ECHO_HD double det_read(const LongParams& p, const unsigned char* smem, int q) {
+    const double* d = reinterpret_cast<const double*>(smem);
+    if (!p.det_view) return d[q];
+    const int j = q - p.det_q0;
+    if (j < 0) return 0.0;
+    const int w = j >= p.cf_V ? 1 : 0, i = j - (w ? p.cf_V : 0);
+    return d[2 * (i + (i >> 3)) + w];
 }
 ECHO_HD DetMisc* det_misc(const LongParams& p, unsigned char* smem) {
     return reinterpret_cast<DetMisc*>(reinterpret_cast<unsigned char*>(det_hist(p, smem)) + 2 * 256 * 4);
+}
+
+ECHO_HD int* det_fhist(const LongParams& p, unsigned char* smem) {
+    return reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(det_hist(p, smem)) + 2 * 256 * 4 + 112);
+}
+ECHO_HD int* det_wtot(const LongParams& p, unsigned char* smem) { return det_fhist(p, smem) + kFsBins; }
+ECHO_HD double* det_list(const LongParams& p, unsigned char* smem) { return reinterpret_cast<double*>(det_wtot(p, smem) + 32); }
+ECHO_HD void det_misc_init(DetMisc* m) {
+    m->first = 0x7fffffff; m->med = 0.0; m->mad = 0.0;
+    m->amax_bits = 0; m->n_neg = 0; m->n_zero = 0; m->n_nan = 0; m->fast = 0; m->nlist = 0;
 }
 
 ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
@@ -273,7 +320,7 @@ ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigne
         else if (p.write_mutated) src[q] = 0.0;
         pos[q] = v;
     }
-    if (tid == 0) { DetMisc* m = det_misc(p, smem); m->first = 0x7fffffff; m->med = 0.0; m->mad = 0.0; }
+    if (tid == 0) det_misc_init(det_misc(p, smem));
 }
 
 // Selection of the element of rank `rank` among key(i) = pos[i] (dev == 0) or |pos[i] - med| (dev == 1): per pass a
@@ -281,7 +328,10 @@ ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigne
 // turn: the idle one is cleared while the other is read), then the bin that holds the rank.  As soon as that bin
 // holds a single element the remaining bits are read off the element itself (ph_sel_find) -- for float64 data that
 // is typically after four of the eight passes.
-ECHO_HD double sel_value(const double* pos, int i, double med, int dev) { return dev ? fabs(pos[i] - med) : pos[i]; }
+ECHO_HD double sel_value(const LongParams& p, const unsigned char* smem, int i, double med, int dev) {
+    const double v = det_read(p, smem, i);
+    return dev ? fabs(v - med) : v;
+}
 ECHO_HD void ph_sel_begin(int tid, const LongParams& p, unsigned char* smem, int rank) {
     if (tid < 512) det_hist(p, smem)[tid] = 0;
     if (tid != 0) return;
@@ -289,7 +339,6 @@ ECHO_HD void ph_sel_begin(int tid, const LongParams& p, unsigned char* smem, int
     m->prefix = 0; m->rank = rank; m->shift = 56; m->cnt = 0; m->nzero = 0;
 }
 ECHO_HD void ph_sel_count(int tid, int nt, const LongParams& p, unsigned char* smem, int dev, int cur) {
-    const double* pos = det_pos(smem);
     DetMisc* m = det_misc(p, smem);
     int* hist = det_hist(p, smem) + 256 * cur;
     const int npos = p.L - p.half, shift = m->shift;
@@ -300,7 +349,7 @@ ECHO_HD void ph_sel_count(int tid, int nt, const LongParams& p, unsigned char* s
         bool match = false, zero = false;
         int digit = 0;
         if (i < npos) {
-            const unsigned long long k = ordered_key(sel_value(pos, i, med, dev));
+            const unsigned long long k = ordered_key(sel_value(p, smem, i, med, dev));
             match = shift == 56 || (k >> (shift + 8)) == (prefix >> (shift + 8));
             digit = (int)((k >> shift) & 255);
             zero = k == kKeyPlusZero;
@@ -364,14 +413,13 @@ ECHO_HD void ph_sel_pick(int tid, const LongParams& p, unsigned char* smem, int 
 }
 // the chosen bin holds one element: it is the wanted one, take all of its bits
 ECHO_HD void ph_sel_find(int tid, int nt, const LongParams& p, unsigned char* smem, int dev) {
-    const double* pos = det_pos(smem);
     DetMisc* m = det_misc(p, smem);
     const int npos = p.L - p.half, shift = m->shift;        // bits above shift + 8 are fixed
     if (shift < 0) return;
     const unsigned long long prefix = m->prefix;
     const double med = m->med;
     for (int i = tid; i < npos; i += nt) {
-        const unsigned long long k = ordered_key(sel_value(pos, i, med, dev));
+        const unsigned long long k = ordered_key(sel_value(p, smem, i, med, dev));
         if ((k >> (shift + 8)) == (prefix >> (shift + 8))) m->prefix = k;      // exactly one element matches
     }
 }
@@ -382,6 +430,127 @@ ECHO_HD void ph_sel_store(int tid, const LongParams& p, unsigned char* smem, int
     const double v = key_value(m->prefix);
     if (which == 0) m->lo = v; else m->hi = v;
 }
+
+// ---- the shortcut.  The blind zone puts min_delay exact zeros into pos and the correlation spreads evenly around
+// zero, so the median of pos is 0.0 whenever the middle ranks fall into the zeros: counting the negative and the zero
+// elements settles that without a selection.  The MAD is then the median of |pos|, and all but a few elements lie
+// within 16 octaves below max|pos|: ONE histogram over bins of 1/128 octave (the top 19 bits of the double, offset so
+// that max|pos| lands in the last bin; smaller elements go to bin 0) locates the bin of the wanted rank, the handful
+// of elements in that bin is collected, and the rank inside the bin is read off by counting.  Exact like the general
+// selection (it picks the same element); whenever an assumption fails -- NaN, median not in the zeros, the rank in
+// bin 0, a crowded bin -- m->fast drops to 0 and the general path runs from the start.
+ECHO_HD unsigned long long fs_bits(double a) { unsigned long long u; __builtin_memcpy(&u, &a, 8); return u; }
+ECHO_HD int fs_bin(unsigned long long bits, int base) {
+    const int b = (int)(bits >> kFsShift) - base;
+    return b < 0 ? 0 : b;
+}
+ECHO_HD void ph_fs_stats(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    DetMisc* m = det_misc(p, smem);
+    int* fh = det_fhist(p, smem);
+    for (int i = tid; i < kFsBins; i += nt) fh[i] = 0;
+    const int npos = p.L - p.half;
+    int nneg = 0, nzero = 0, nnan = 0;
+    unsigned long long amax = 0;
+    for (int q = p.min_delay + tid; q < npos; q += nt) {
+        const double v = det_read(p, smem, q);
+        nneg += v < 0.0 ? 1 : 0; nzero += v == 0.0 ? 1 : 0; nnan += v != v ? 1 : 0;
+        const unsigned long long b = fs_bits(fabs(v));
+        amax = b > amax ? b : amax;
+    }
+    ECHO_WAVE_SUM_ADD(&m->n_neg, nneg);
+    ECHO_WAVE_SUM_ADD(&m->n_zero, nzero);
+    ECHO_WAVE_SUM_ADD(&m->n_nan, nnan);
+    ECHO_WAVE_MAX_U64(&m->amax_bits, amax);
+}
+ECHO_HD void ph_fs_decide(int tid, const LongParams& p, unsigned char* smem, int two) {
+    if (tid != 0) return;
+    DetMisc* m = det_misc(p, smem);
+    const int npos = p.L - p.half;
+    const int zeros = m->n_zero + (p.min_delay < npos ? p.min_delay : npos);
+    const int r0 = two ? npos / 2 - 1 : npos / 2, r1 = npos / 2;
+    const bool med_zero = m->n_nan == 0 && r0 >= m->n_neg && r1 < m->n_neg + zeros;
+    if (!med_zero) { m->fast = 0; return; }
+    m->med = 0.0;
+    if (m->amax_bits == 0) { m->fast = 2; m->lo = 0.0; m->hi = 0.0; return; }   // silence: |pos| is all zero
+    m->fast = 1;
+    m->base = (int)(m->amax_bits >> kFsShift) - (kFsBins - 1);
+    det_fhist(p, smem)[0] = p.min_delay < npos ? p.min_delay : npos;             // the blind zone
+}
+ECHO_HD void ph_fs_hist(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    const DetMisc* m = det_misc(p, smem);
+    int* fh = det_fhist(p, smem);
+    const int npos = p.L - p.half, base = m->base;
+    for (int q = p.min_delay + tid; q < npos; q += nt)
+        ECHO_LDS_ADD(&fh[fs_bin(fs_bits(fabs(det_read(p, smem, q))), base)], 1);
+}
+// the bin that holds the rank: totals per wavefront, then every thread scans its own run of bins
+ECHO_HD void ph_fs_scan_a(int tid, int nt, const LongParams& p, unsigned char* smem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int* fh = det_fhist(p, smem);
+    const int per = kFsBins / nt;
+    int c = 0;
+    for (int e = 0; e < per; ++e) c += fh[tid * per + e];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((tid & 63) == 0) det_wtot(p, smem)[tid >> 6] = c;
+#endif
+    if (tid == 0) det_misc(p, smem)->nlist = 0;
+}
+ECHO_HD void fs_chosen(DetMisc* m, int bin, int below, int cnt) {
+    m->bin = bin; m->below = below; m->cnt = cnt;
+    if (bin == 0 || cnt > kFsList) m->fast = 0;
+}
+ECHO_HD void ph_fs_scan_b(int tid, int nt, const LongParams& p, unsigned char* smem, int rank) {
+    DetMisc* m = det_misc(p, smem);
+    const int* fh = det_fhist(p, smem);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int per = kFsBins / nt, lane = tid & 63, wave = tid >> 6;
+    int c = 0;
+    for (int e = 0; e < per; ++e) c += fh[tid * per + e];
+    int inc = c;
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    const int* wt = det_wtot(p, smem);
+    int exc = inc - c;
+    for (int w = 0; w < wave; ++w) exc += wt[w];
+    if (exc <= rank && rank < exc + c) {                    // one thread
+        int cum = exc;
+        for (int e = 0; e < per; ++e) {
+            const int h = fh[tid * per + e];
+            if (rank < cum + h) { fs_chosen(m, tid * per + e, cum, h); break; }
+            cum += h;
+        }
+    }
+#else
+    if (tid != 0) return;
+    int cum = 0, b = 0;
+    for (; b < kFsBins - 1; ++b) { if (rank < cum + fh[b]) break; cum += fh[b]; }
+    fs_chosen(m, b, cum, fh[b]);
+#endif
+}
+ECHO_HD void ph_fs_collect(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    DetMisc* m = det_misc(p, smem);
+    double* list = det_list(p, smem);
+    const int npos = p.L - p.half, base = m->base, bin = m->bin;
+    for (int q = p.min_delay + tid; q < npos; q += nt) {
+        const double a = fabs(det_read(p, smem, q));
+        if (fs_bin(fs_bits(a), base) == bin) {
+            const int slot = ECHO_LDS_FETCH_ADD(&m->nlist, 1);
+            if (slot < kFsList) list[slot] = a;
+        }
+    }
+}
+// the element of rank (rank - below) among the collected ones: the one with at most that many smaller and more than
+// that many smaller-or-equal elements (equal elements all write the same value)
+ECHO_HD void ph_fs_pick(int tid, const LongParams& p, unsigned char* smem, int rank, int which) {
+    DetMisc* m = det_misc(p, smem);
+    const double* list = det_list(p, smem);
+    const int n = m->nlist < kFsList ? m->nlist : kFsList, k = rank - m->below;
+    if (tid >= n) return;
+    const double x = list[tid];
+    int less = 0, leq = 0;
+    for (int j = 0; j < n; ++j) { const double y = list[j]; less += y < x ? 1 : 0; leq += y <= x ? 1 : 0; }
+    if (less <= k && k < leq) { if (which == 0) m->lo = x; else m->hi = x; }
+}
+
 // np.median: the middle element, or the mean of the two middle elements ((a + b) / 2)
 ECHO_HD void ph_ldet_set_med(int tid, const LongParams& p, unsigned char* smem, int two) {
     if (tid != 0) return;
@@ -394,14 +563,14 @@ ECHO_HD void ph_ldet_set_mad(int tid, const LongParams& p, unsigned char* smem, 
     m->mad = (two ? (m->lo + m->hi) / 2.0 : m->lo) + 1e-9;
 }
 ECHO_HD void ph_ldet_cross(int tid, int nt, const LongParams& p, unsigned char* smem) {
-    const double* pos = det_pos(smem);
+#pragma clang fp contract(off)   // med + 6 * mad rounds twice, as numpy does, also where the file allows contraction
     DetMisc* m = det_misc(p, smem);
     const int npos = p.L - p.half;
     const double six_mad = 6.0 * m->mad;
     const double thr = m->med + six_mad;
     int first = 0x7fffffff;
     for (int q = tid; q < npos; q += nt)
-        if (pos[q] > thr) { first = q; break; }
+        if (det_read(p, smem, q) > thr) { first = q; break; }
     if (first != 0x7fffffff) ECHO_LDS_MIN(&m->first, first);
 }
 ECHO_HD void ph_ldet_finish(int tid, int blk, const LongParams& p, unsigned char* smem) {
@@ -621,24 +790,51 @@ ECHO_HD void ph_lm_finish(int tid, int nt, int blk, const LongParams& p, unsigne
                                                   r_.pad = 0; r_.peak_idx = -1; (p).res_out[blk] = r_; }) \
             break;                                                                                      \
         }                                                                                               \
-        const int two_ = (npos_ % 2 == 0) ? 1 : 0;                                                      \
         PHASE(ph_ldet_load(tid, nt, blk, p, smem)) SYNC                                                 \
-        const int nsel_ = (p).det_stages > 0 && (p).det_stages < 3 ? (p).det_stages - 1 : 2;            \
-        const int npass_ = (p).det_passes > 0 && (p).det_passes < 8 ? (p).det_passes : 8;               \
-        for (int dev_ = 0; dev_ < nsel_; ++dev_) {                                                      \
-            for (int w_ = 0; w_ <= two_; ++w_) {                                                        \
-                const int rank_ = two_ ? npos_ / 2 - 1 + w_ : npos_ / 2;                                \
-                PHASE(ph_sel_begin(tid, p, smem, rank_)) SYNC                                           \
-                for (int pass_ = 0; pass_ < npass_; ++pass_) {                                          \
-                    PHASE(ph_sel_count(tid, nt, p, smem, dev_, pass_ & 1)) SYNC                         \
-                    PHASE(ph_sel_pick(tid, p, smem, pass_ & 1)) SYNC                                    \
-                    if (det_misc(p, smem)->cnt == 1) break;                                             \
+        ECHO_LDET_BODY(PHASE, SYNC, p, smem, blk, nt);                                                  \
+    } while (0)
+
+// the detector on a pos that is in LDS already (det_view, det_lds_off say where), scalars initialised
+#define ECHO_LDET_BODY(PHASE, SYNC, p, smem, blk, nt)                                                   \
+    do {                                                                                                \
+        const int npos_ = (p).L - (p).half;                                                             \
+        const int two_ = (npos_ % 2 == 0) ? 1 : 0;                                                      \
+        const bool all_ = !((p).det_stages > 0 && (p).det_stages < 3) && !((p).det_passes > 0 && (p).det_passes < 8); \
+        if (all_) {                                                                                     \
+            PHASE(ph_fs_stats(tid, nt, p, smem)) SYNC                                                   \
+            PHASE(ph_fs_decide(tid, p, smem, two_)) SYNC                                                \
+            if (det_misc(p, smem)->fast == 1) {                                                         \
+                PHASE(ph_fs_hist(tid, nt, p, smem)) SYNC                                                \
+                for (int w_ = 0; w_ <= two_; ++w_) {                                                    \
+                    const int rank_ = two_ ? npos_ / 2 - 1 + w_ : npos_ / 2;                            \
+                    PHASE(ph_fs_scan_a(tid, nt, p, smem)) SYNC                                          \
+                    PHASE(ph_fs_scan_b(tid, nt, p, smem, rank_)) SYNC                                   \
+                    if (det_misc(p, smem)->fast != 1) break;                                            \
+                    PHASE(ph_fs_collect(tid, nt, p, smem)) SYNC                                         \
+                    PHASE(ph_fs_pick(tid, p, smem, rank_, w_)) SYNC                                     \
                 }                                                                                       \
-                PHASE(ph_sel_find(tid, nt, p, smem, dev_)) SYNC                                         \
-                PHASE(ph_sel_store(tid, p, smem, w_)) SYNC                                              \
             }                                                                                           \
-            PHASE(if (dev_ == 0) ph_ldet_set_med(tid, p, smem, two_);                                   \
-                  else ph_ldet_set_mad(tid, p, smem, two_)) SYNC                                        \
+        }                                                                                               \
+        if (all_ && det_misc(p, smem)->fast != 0) {                                                     \
+            PHASE(ph_ldet_set_mad(tid, p, smem, two_)) SYNC                                             \
+        } else {                                                                                        \
+            const int nsel_ = (p).det_stages > 0 && (p).det_stages < 3 ? (p).det_stages - 1 : 2;        \
+            const int npass_ = (p).det_passes > 0 && (p).det_passes < 8 ? (p).det_passes : 8;           \
+            for (int dev_ = 0; dev_ < nsel_; ++dev_) {                                                  \
+                for (int w_ = 0; w_ <= two_; ++w_) {                                                    \
+                    const int rank_ = two_ ? npos_ / 2 - 1 + w_ : npos_ / 2;                            \
+                    PHASE(ph_sel_begin(tid, p, smem, rank_)) SYNC                                       \
+                    for (int pass_ = 0; pass_ < npass_; ++pass_) {                                      \
+                        PHASE(ph_sel_count(tid, nt, p, smem, dev_, pass_ & 1)) SYNC                     \
+                        PHASE(ph_sel_pick(tid, p, smem, pass_ & 1)) SYNC                                \
+                        if (det_misc(p, smem)->cnt == 1) break;                                         \
+                    }                                                                                   \
+                    PHASE(ph_sel_find(tid, nt, p, smem, dev_)) SYNC                                     \
+                    PHASE(ph_sel_store(tid, p, smem, w_)) SYNC                                          \
+                }                                                                                       \
+                PHASE(if (dev_ == 0) ph_ldet_set_med(tid, p, smem, two_);                               \
+                      else ph_ldet_set_mad(tid, p, smem, two_)) SYNC                                    \
+            }                                                                                           \
         }                                                                                               \
         PHASE(ph_ldet_cross(tid, nt, p, smem)) SYNC                                                     \
         PHASE(ph_ldet_finish(tid, blk, p, smem))                                                        \

@@ -354,6 +354,64 @@ def test_original_variant_goldens_and_oracle(gold_original):
     e.close()
 
 
+def test_original_chain_detects_inside_the_matched_filter_kernel(gold_original, monkeypatch):
+    """airSonar.py parameters: the chain runs the matched filter and the median/MAD first crossing in one kernel (the
+    correlation stays in LDS).  Its records must be byte-identical to the two kernels with the correlation handed
+    over through memory (ECHO_FUSE_DET=0), on the golden frames and on synthetic ones -- among them frames of
+    silence, whose median and MAD are zero, and a frame count that is no multiple of anything."""
+    from dsp_amd.engine import BatchedKalman
+    cfg = C.original_config()
+    t = build_tables(cfg)
+    rxs = np.concatenate([rx_from_i16(gold_original["rx_i16"]), synth_frames(157, cfg, t.tx_pcm)])
+    rxs[5] = 0.0
+    rxs[6, : cfg.n_rx // 2] = 0.0
+    fused = _engine(cfg)
+    monkeypatch.setenv("ECHO_FUSE_DET", "0")
+    apart = _engine(cfg)
+    monkeypatch.delenv("ECHO_FUSE_DET")
+    a, spec_a = fused.chain(rxs, n_streams=1, kalman=BatchedKalman(fused, 1), want_spectra=True)
+    b, spec_b = apart.chain(rxs, n_streams=1, kalman=BatchedKalman(apart, 1), want_spectra=True)
+    assert torch.equal(a, b) and torch.equal(spec_a, spec_b)
+    assert (_rec(a)["peak_idx"] >= 0).any()
+    fused.close(); apart.close()
+
+
+def test_mad_detector_shortcut_and_general_selection_against_oracle():
+    """first_strong_peak of airSonar.py (median/MAD first crossing, :104-117) on crafted correlations of the original
+    parameter set's size.  Most frames take the kernel's shortcut (median of pos settled by counting the blind zone's
+    zeros, MAD by one histogram); the others break one of its assumptions each and must come out of the general radix
+    selection with the same exact index."""
+    cfg = C.original_config()
+    e = _engine(cfg)
+    rng = np.random.default_rng(5)
+    nb, L, half = cfg.n_bands, cfg.n_corr, cfg.half
+    npos = L - half
+    B = 8
+    c = rng.standard_normal((B, nb, L)) * 1e-3
+    c[0, 0, half + 900] = 0.5                                      # one clear echo
+    c[0, 1, half + 100] = 2.0; c[0, 1, half + 1500] = 0.3          # strongest sample inside the blind zone
+    c[0, 2, half + 700] = 0.4; c[0, 2, half + 1900] = 0.4          # tie: first index wins
+    c[1, 0] = 0.0                                                  # silence
+    c[1, 1, half + npos - 1] = 1.0                                 # crossing at the last lag
+    c[1, 2] *= 1e-300                                              # tiny magnitudes
+    c[2, 0] += 2e-3                                                # median of pos away from zero
+    c[2, 1, half + 1000:] = 0.0                                    # MAD rank among the zeros
+    c[2, 2] = np.where(c[2, 2] < 0, -1e-3, 1e-3); c[2, 2, half + 2000] = 0.1       # one magnitude for every lag
+    c[3, 0] = np.round(c[3, 0] * 2e3) / 2e3                        # few distinct magnitudes, many zeros
+    c[3, 1, half + 3000] = 1e6                                     # median of |pos| more than 16 octaves below the maximum
+    c[3, 2] = np.abs(c[3, 2])                                      # no negative lag at all
+    for b in range(4, B):                                          # echoes over noise of various levels
+        for j in range(nb):
+            c[b, j] *= 10.0 ** rng.uniform(-3, 2)
+            c[b, j, half + int(rng.integers(cfg.min_delay, npos))] += 0.5
+    want = np.array([[(-1 if (w := O.first_strong_peak_mad(c[b, j].copy(), cfg.FS, cfg.min_delay)) is None else w)
+                      for j in range(nb)] for b in range(B)])
+    peak, _, _ = e.first_strong_peak(torch.from_numpy(c.copy()).to(e.device))
+    assert np.array_equal(peak.cpu().numpy(), want)
+    assert (want >= 0).sum() >= 12 and (want < 0).any()
+    e.close()
+
+
 @pytest.mark.parametrize("which", ["original", "twopeak"])
 def test_long_matched_filter_fft_against_exact_direct_sum(which):
     """echo_correlate of the long-frame parameter sets (overlap-save FFT in LDS, float64) against the exact direct sum

@@ -156,6 +156,10 @@ def test_emulated_long_frame_detectors_against_oracle(emul):
         c[1, 1] = 0.0                                              # silence
         c[2, 0, : half] *= 500.0                                   # amplitude dominated by the first half
         c[2, 1, half + npos - 1] = 1.0                             # peak at the last lag
+        c[3, 0] += 2e-3                                            # median of pos away from zero
+        c[3, 1, half + 1000:] = 0.0                                # more than half of pos is zero: MAD rank in the zeros
+        c[4, 0] = np.where(c[4, 0] < 0, -1e-3, 1e-3); c[4, 0, half + 2000] = 0.1    # one magnitude shared by every lag
+        c[4, 1] = np.round(c[4, 1] * 2e3) / 2e3                    # a few distinct magnitudes, many exact zeros
         return c
 
     for det, min_delay, noise_n in ((0, 331, 240), (0, 2300, 240), (2, 164, int(npos * 0.2)), (1, 500, 0), (3, 0, int(npos * 0.2))):
