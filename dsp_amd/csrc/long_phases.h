@@ -36,19 +36,19 @@ __device__ __forceinline__ void wave_hist_add(int* hist, int digit, bool active)
     do { const unsigned long long b_ = __ballot(flag);                                        \
          if (b_ && __lane_id() == 0) atomicAdd((counter), (int)__popcll(b_)); } while (0)
 #define ECHO_LDS_FETCH_ADD(p, v) atomicAdd((p), (v))
-// *counter += sum of v over the wavefront / *ptr = max(*ptr, v over the wavefront) (all lanes must call): one atomic each
-#define ECHO_WAVE_SUM_ADD(counter, v)                                                         \
-    do { int s_ = (v);                                                                        \
-         for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_);                        \
-         if (s_ && __lane_id() == 0) atomicAdd((counter), s_); } while (0)
-#define ECHO_WAVE_MAX_U64(ptr, v)                                                             \
-    do { unsigned long long s_ = (v);                                                         \
-         for (int o_ = 32; o_ > 0; o_ >>= 1) { const unsigned long long t_ = __shfl_xor(s_, o_); s_ = t_ > s_ ? t_ : s_; } \
-         if (s_ && __lane_id() == 0) atomicMax((ptr), s_); } while (0)
+// maximum of v over the wavefront, in every lane: DPP exchanges inside rows of 16 lanes, two shuffles across rows
+__device__ __forceinline__ int wave_max_int(int v) {
+    int t;
+    t = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); v = t > v ? t : v;    // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true); v = t > v ? t : v;    // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true); v = t > v ? t : v;   // row_half_mirror
+    t = __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true); v = t > v ? t : v;   // row_mirror
+    t = __shfl_xor(v, 16); v = t > v ? t : v;
+    t = __shfl_xor(v, 32); v = t > v ? t : v;
+    return v;
+}
 #else
 #define ECHO_LDS_FETCH_ADD(p, v) ((*(p) += (v)) - (v))
-#define ECHO_WAVE_SUM_ADD(counter, v) (*(counter) += (v))
-#define ECHO_WAVE_MAX_U64(ptr, v) do { if ((v) > *(ptr)) *(ptr) = (v); } while (0)
 #define ECHO_LDS_ADD(p, v) (*(p) += (v))
 #define ECHO_LDS_MIN(p, v) (*(p) = (v) < *(p) ? (v) : *(p))
 #define ECHO_HIST_ADD(hist, digit, active) do { if (active) (hist)[(digit)] += 1; } while (0)
@@ -116,7 +116,7 @@ struct DetMisc {                     // detector scalars in LDS
     int rank, shift, first, cnt;     // cnt: elements left in the chosen bin
     int nzero, pad;                  // nzero: elements equal to +0.0 (counted in the first pass)
     // the shortcut (ph_fs_*): statistics of pos beyond the blind zone, and the state of the selection by one histogram
-    unsigned long long amax_bits;    // bit image of max |pos|
+    int amax_hi, pad1;               // upper 32 bits of the double max |pos|
     int n_neg, n_zero, n_nan;        // negative, zero and NaN elements
     int fast;                        // 1: the shortcut's assumptions hold so far; 2: pos is all zero; 0: take the general path
     int bin, below, nlist, base;     // chosen bin, elements in lower bins, collected elements, (key >> kFsShift) of bin 0
@@ -307,7 +307,7 @@ ECHO_HD int* det_wtot(const LongParams& p, unsigned char* smem) { return det_fhi
 ECHO_HD double* det_list(const LongParams& p, unsigned char* smem) { return reinterpret_cast<double*>(det_wtot(p, smem) + 32); }
 ECHO_HD void det_misc_init(DetMisc* m) {
     m->first = 0x7fffffff; m->med = 0.0; m->mad = 0.0;
-    m->amax_bits = 0; m->n_neg = 0; m->n_zero = 0; m->n_nan = 0; m->fast = 0; m->nlist = 0;
+    m->amax_hi = 0; m->n_neg = 0; m->n_zero = 0; m->n_nan = 0; m->fast = 0; m->nlist = 0;
 }
 
 ECHO_HD void ph_ldet_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
@@ -449,32 +449,60 @@ ECHO_HD void ph_fs_stats(int tid, int nt, const LongParams& p, unsigned char* sm
     int* fh = det_fhist(p, smem);
     for (int i = tid; i < kFsBins; i += nt) fh[i] = 0;
     const int npos = p.L - p.half;
-    int nneg = 0, nzero = 0, nnan = 0;
-    unsigned long long amax = 0;
+    int nneg = 0, nzero = 0, nnan = 0, amax = 0;             // amax: the upper word of the largest |pos|
+#if defined(__HIP_DEVICE_COMPILE__)
+    // counts as wavefront-wide population counts (scalar registers, nothing to reduce at the end); the trip count is
+    // the same for every lane of a wavefront
+    for (int q0 = p.min_delay + (tid & ~63); q0 < npos; q0 += 4 * nt) {   // four independent reads at a time
+        double v[4];
+        bool in[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = q0 + e * nt + (tid & 63);
+            in[e] = q < npos; v[e] = in[e] ? det_read(p, smem, q) : 1.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            nneg += (int)__popcll(__ballot(v[e] < 0.0));
+            nzero += (int)__popcll(__ballot(v[e] == 0.0));
+            nnan += (int)__popcll(__ballot(v[e] != v[e]));
+            const int hi = in[e] ? (int)(fs_bits(fabs(v[e])) >> 32) : 0;
+            amax = hi > amax ? hi : amax;
+        }
+    }
+    amax = wave_max_int(amax);
+    if ((tid & 63) == 0) {
+        if (nneg) atomicAdd(&m->n_neg, nneg);
+        if (nzero) atomicAdd(&m->n_zero, nzero);
+        if (nnan) atomicAdd(&m->n_nan, nnan);
+        if (amax) atomicMax(&m->amax_hi, amax);
+    }
+#else
     for (int q = p.min_delay + tid; q < npos; q += nt) {
         const double v = det_read(p, smem, q);
         nneg += v < 0.0 ? 1 : 0; nzero += v == 0.0 ? 1 : 0; nnan += v != v ? 1 : 0;
-        const unsigned long long b = fs_bits(fabs(v));
-        amax = b > amax ? b : amax;
+        const int hi = (int)(fs_bits(fabs(v)) >> 32);
+        amax = hi > amax ? hi : amax;
     }
-    ECHO_WAVE_SUM_ADD(&m->n_neg, nneg);
-    ECHO_WAVE_SUM_ADD(&m->n_zero, nzero);
-    ECHO_WAVE_SUM_ADD(&m->n_nan, nnan);
-    ECHO_WAVE_MAX_U64(&m->amax_bits, amax);
+    m->n_neg += nneg; m->n_zero += nzero; m->n_nan += nnan;
+    if (amax > m->amax_hi) m->amax_hi = amax;
+#endif
 }
 ECHO_HD void ph_fs_decide(int tid, const LongParams& p, unsigned char* smem, int two) {
     if (tid != 0) return;
     DetMisc* m = det_misc(p, smem);
     const int npos = p.L - p.half;
-    const int zeros = m->n_zero + (p.min_delay < npos ? p.min_delay : npos);
+    const int blind = p.min_delay < npos ? p.min_delay : npos;
+    const int zeros = m->n_zero + blind;
     const int r0 = two ? npos / 2 - 1 : npos / 2, r1 = npos / 2;
     const bool med_zero = m->n_nan == 0 && r0 >= m->n_neg && r1 < m->n_neg + zeros;
     if (!med_zero) { m->fast = 0; return; }
     m->med = 0.0;
-    if (m->amax_bits == 0) { m->fast = 2; m->lo = 0.0; m->hi = 0.0; return; }   // silence: |pos| is all zero
+    if (zeros == npos) { m->fast = 2; m->lo = 0.0; m->hi = 0.0; return; }   // silence: |pos| is all zero
+    if (m->amax_hi == 0) { m->fast = 0; return; }                          // nothing but denormals: the general path
     m->fast = 1;
-    m->base = (int)(m->amax_bits >> kFsShift) - (kFsBins - 1);
-    det_fhist(p, smem)[0] = p.min_delay < npos ? p.min_delay : npos;             // the blind zone
+    m->base = (m->amax_hi >> (kFsShift - 32)) - (kFsBins - 1);
+    det_fhist(p, smem)[0] = blind;                                          // the blind zone
 }
 ECHO_HD void ph_fs_hist(int tid, int nt, const LongParams& p, unsigned char* smem) {
     const DetMisc* m = det_misc(p, smem);
@@ -530,12 +558,16 @@ ECHO_HD void ph_fs_collect(int tid, int nt, const LongParams& p, unsigned char* 
     DetMisc* m = det_misc(p, smem);
     double* list = det_list(p, smem);
     const int npos = p.L - p.half, base = m->base, bin = m->bin;
-    for (int q = p.min_delay + tid; q < npos; q += nt) {
-        const double a = fabs(det_read(p, smem, q));
-        if (fs_bin(fs_bits(a), base) == bin) {
-            const int slot = ECHO_LDS_FETCH_ADD(&m->nlist, 1);
-            if (slot < kFsList) list[slot] = a;
-        }
+    for (int q = p.min_delay + tid; q < npos; q += 4 * nt) {   // four independent reads at a time
+        double a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = q + e * nt < npos ? fabs(det_read(p, smem, q + e * nt)) : -1.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (a[e] >= 0.0 && fs_bin(fs_bits(a[e]), base) == bin) {
+                const int slot = ECHO_LDS_FETCH_ADD(&m->nlist, 1);
+                if (slot < kFsList) list[slot] = a[e];
+            }
     }
 }
 // the element of rank (rank - below) among the collected ones: the one with at most that many smaller and more than
@@ -569,8 +601,13 @@ ECHO_HD void ph_ldet_cross(int tid, int nt, const LongParams& p, unsigned char* 
     const double six_mad = 6.0 * m->mad;
     const double thr = m->med + six_mad;
     int first = 0x7fffffff;
-    for (int q = tid; q < npos; q += nt)
-        if (det_read(p, smem, q) > thr) { first = q; break; }
+    for (int q = tid; q < npos && first == 0x7fffffff; q += 4 * nt) {   // four independent reads at a time
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = q + e * nt < npos ? det_read(p, smem, q + e * nt) : thr;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) if (v[e] > thr) first = q + e * nt;
+    }
     if (first != 0x7fffffff) ECHO_LDS_MIN(&m->first, first);
 }
 ECHO_HD void ph_ldet_finish(int tid, int blk, const LongParams& p, unsigned char* smem) {
