@@ -2,7 +2,9 @@
 """Larger parity run: the GPU chain against the oracle on many synthetic frames (named and full chain, both band
 sets).  The oracle runs in worker processes on frame shards (they never touch the GPU); the parent runs the GPU chain,
 replays the Kalman filter over the oracle's fused ranges and writes a JSON summary.
-Usage: bulk_parity.py [frames] [workers] [out.json] [lanes]; exits non-zero on any index or validity mismatch.
+Usage: bulk_parity.py [frames] [workers] [out.json] [lanes] [variant]; exits non-zero on any index or validity
+mismatch.  variant: optimized (default: both band sets, named and full chain), or original / twopeak / realtime (the
+other parameter sets, named chain).
 With lanes > 1 the GPU side runs as batches of 4096 frames in flight on that many streams (ChainLanes), which also
 checks that concurrent handles do not disturb each other."""
 import json
@@ -19,6 +21,12 @@ START = 100000
 CHUNK = 500
 
 
+def _config(which):
+    from dsp_amd import config as C
+    return {"default": lambda: C.optimized_config(C.BANDS_DEFAULT), "distinct": lambda: C.optimized_config(C.BANDS_DISTINCT),
+            "original": C.original_config, "twopeak": C.twopeak_config, "realtime": C.realtime_config}[which]()
+
+
 def _oracle_shard(job):
     which, mode, lo, n = job
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -27,7 +35,7 @@ def _oracle_shard(job):
     from dsp_amd.design import build_tables
     from dsp_amd.synth import synth_frames
     from oracle import echo_oracle as O
-    cfg = C.optimized_config(C.BANDS_DEFAULT if which == "default" else C.BANDS_DISTINCT)
+    cfg = _config(which)
     t = build_tables(cfg)
     rx = synth_frames(n, cfg, t.tx_pcm, start=START + lo)
     o = O.chain(rx, t.chirps_f32, t.filters, cfg, n_streams=n, mode=mode)
@@ -39,21 +47,23 @@ def main():
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else min(16, os.cpu_count() or 1)
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
     n_lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    variant = sys.argv[5] if len(sys.argv) > 5 else "optimized"
+    legs = [("default", ("named", "full")), ("distinct", ("named", "full"))] if variant == "optimized" else [(variant, ("named",))]
     from dsp_amd import config as C
     from dsp_amd.engine import BatchedKalman, EchoEngine, records_to_numpy
     from dsp_amd.synth import synth_frames
     from oracle import echo_oracle as O
     S = 64
     n -= n % S
-    summary = {"lanes": n_lanes, "frames_per_leg": n, "first_frame_seed_index": START, "n_streams": S, "oracle_workers": workers, "legs": []}
+    summary = {"variant": variant, "lanes": n_lanes, "frames_per_leg": n, "first_frame_seed_index": START, "n_streams": S, "oracle_workers": workers, "legs": []}
     bad = 0
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
-        for which in ("default", "distinct"):
-            cfg = C.optimized_config(C.BANDS_DEFAULT if which == "default" else C.BANDS_DISTINCT)
+        for which, modes in legs:
+            cfg = _config(which)
             eng = EchoEngine(cfg)
             rx = synth_frames(n, cfg, eng.tables.tx_pcm, start=START)
-            for mode in ("named", "full"):
+            for mode in modes:
                 t0 = time.time()
                 jobs = [(which, mode, lo, min(CHUNK, n - lo)) for lo in range(0, n, CHUNK)]
                 o = {}
@@ -87,17 +97,22 @@ def main():
                 v = o["valid"]
                 if mode == "full":      # the oracle's full-chain index: recovered from the distance (an index into corr)
                     want_idx = np.rint(o["distance"] * 2 * cfg.FS / cfg.sound_speed).astype(np.int64) + cfg.range_offset
-                    mism = int((r["peak_idx"][:, :3][v] != want_idx[v]).sum())
+                    diff = (r["peak_idx"][:, :3] != want_idx) & v
                 else:
-                    mism = int((r["peak_idx"][:, :3] != o["peak_idx"]).sum())
+                    want_idx = o["peak_idx"]
+                    diff = r["peak_idx"][:, :3] != want_idx
+                mism = int(diff.sum())
+                where = [[int(i), int(j), int(r["peak_idx"][i, j]), int(want_idx[i, j])] for i, j in zip(*np.nonzero(diff))][:50]
                 vmism = int((valid != v).sum())
                 rel = lambda a, b: float((np.abs(a - b) / np.maximum(np.abs(b), 1e-12)).max()) if len(b) else 0.0
                 leg = {"bands": which, "mode": mode, "frames": n, "frame_bands": int(n * 3), "valid_frame_bands": int(v.sum()),
                        "index_mismatches": mism, "validity_mismatches": vmism,
+                       "index_mismatch_list_frame_band_got_want": where,
                        "max_rel_err_snr": rel(r["snr_db"][:, :3][v], o["snr_db"][v]),
                        "max_rel_err_confidence": rel(r["conf"][:, :3][v], o["confidence"][v]),
                        "max_rel_err_distance": rel(r["dist"][:, :3][v], o["distance"][v]),
                        "max_rel_err_fused": rel(r["fused_dist"][o["valid_any"]], o["fused_dist"][o["valid_any"]]),
+                       "max_abs_err_fused": float(np.abs(r["fused_dist"][o["valid_any"]] - o["fused_dist"][o["valid_any"]]).max()) if o["valid_any"].any() else 0.0,
                        "max_abs_err_kalman": float(np.abs(r["kalman"] - kal).max()), "oracle_seconds": round(time.time() - t0, 1)}
                 print(json.dumps(leg), flush=True)
                 summary["legs"].append(leg)
