@@ -30,7 +30,20 @@ __global__ __launch_bounds__(kCfNT) void long_corr_det_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
+__global__ __launch_bounds__(kCfNT) void long_corr_tp_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_CF_TP_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kCfNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
 int cfft_kernel_prepare() {
+    static_assert(sizeof(TpMisc) <= 64 && kLDetNT <= kCfNT, "two-peak detector behind the transform");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_tp_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kCfDetSmem) != hipSuccess) return ECHO_ERR_HIP;
     static_assert(kCfDetSmem <= 160 * 1024, "transform and detector scratch exceed the LDS of a compute unit");
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(long_corr_det_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kCfDetSmem) != hipSuccess) return ECHO_ERR_HIP;
@@ -38,10 +51,12 @@ int cfft_kernel_prepare() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, kCfSmem) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
 }
 
-// true when launch_long_corr_det can replace launch_long_corr + launch_long_detect for these parameters
+// true when launch_long_corr_det can replace launch_long_corr + launch_long_detect for these parameters (MAD and
+// two-peak detectors, all wanted lags in one pair of sub-blocks)
 bool long_corr_det_fits(const LongParams& p) {
-    return p.cf_use && p.cf_g && p.cf_w2 && p.cf_tw && p.detector == ECHO_DET_MAD && p.L - p.half > p.min_delay &&
-           p.k_begin == p.half + p.min_delay && cf_pairs(p) == 1;
+    if (!p.cf_use || !p.cf_g || !p.cf_w2 || !p.cf_tw || cf_pairs(p) != 1) return false;
+    if (p.detector == ECHO_DET_MAD) return p.L - p.half > p.min_delay && p.k_begin == p.half + p.min_delay;
+    return p.detector == ECHO_DET_TWOPEAK && p.k_begin == 0 && p.L - p.half > 0;
 }
 
 int launch_long_corr_det(const LongParams& q, int B, hipStream_t s) {
@@ -49,7 +64,8 @@ int launch_long_corr_det(const LongParams& q, int B, hipStream_t s) {
     LongParams p = q;
     if (!long_corr_det_fits(p) || !p.res_out) return ECHO_ERR_INVALID;
     p.det_view = 1; p.det_q0 = p.k_begin - p.half; p.det_lds_off = kCfSmem;
-    hipLaunchKernelGGL(long_corr_det_kernel, dim3(B * p.nb), dim3(kCfNT), kCfDetSmem, s, p);
+    if (p.detector == ECHO_DET_TWOPEAK) hipLaunchKernelGGL(long_corr_tp_kernel, dim3(B * p.nb), dim3(kCfNT), kCfDetSmem, s, p);
+    else hipLaunchKernelGGL(long_corr_det_kernel, dim3(B * p.nb), dim3(kCfNT), kCfDetSmem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
 }
 

@@ -21,7 +21,8 @@ constexpr int kCfF = 8192;                       // cyclic length (complex point
 constexpr int kCfNT = 1024;                      // threads per workgroup: one radix-8 butterfly each
 constexpr int kCfSlots = kCfF + kCfF / 8;        // padded LDS slots
 constexpr int kCfSmem = kCfSlots * 16;
-constexpr int kCfDetSmem = kCfSmem + kDetExtra;   // with the detector's histograms and scalars behind the transform
+constexpr int kCfTpExtra = 3 * kLDetNT * 8 + 64;           // two-peak detector: per-thread partials and scalars
+constexpr int kCfDetSmem = kCfSmem + (kDetExtra > kCfTpExtra ? kDetExtra : kCfTpExtra);   // with the detector's histograms and scalars behind the transform
 constexpr int kCfTwLen = 3 * (512 + 64 + 8);     // pass twiddles: per stride q the runs W^i, W^2i, W^4i (i < q), W = exp(-2 pi i/(8q))
 
 typedef cpx<double> zd;
@@ -178,6 +179,18 @@ ECHO_HD void ph_cf_finish_inplace(int tid, int nt, const LongParams& p, unsigned
     ECHO_CF_TRANSFORM(PHASE, SYNC, p, smem, 0, blk, nt)                             \
     PHASE(ph_cf_finish_inplace(tid, nt, p, smem)) SYNC                              \
     ECHO_LDET_BODY(PHASE, SYNC, p, smem, blk, nt)
+
+// matched filter and the two-peak detector (666.py:153-200) in one workgroup.  The detector's phases run on the first
+// kLDetNT threads, so that its sums are formed in the order of the detector kernel
+#define ECHO_CF_TP_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                     \
+    ECHO_CF_TRANSFORM(PHASE, SYNC, p, smem, 0, blk, nt)                                         \
+    PHASE(ph_cf_finish_inplace(tid, nt, p, smem)) SYNC                                          \
+    PHASE(if (tid < kLDetNT) ph_tp_scan_view(tid, kLDetNT, p, smem)) SYNC                       \
+    PHASE(if (tid < kLDetNT) ph_tp_ref_fold(tid, kLDetNT, p, smem)) SYNC                        \
+    PHASE(if (tid < kLDetNT) ph_tp_ref(tid, kLDetNT, p, smem)) SYNC                             \
+    PHASE(if (tid < kLDetNT) ph_tp_second(tid, kLDetNT, p, smem)) SYNC                          \
+    PHASE(if (tid < kLDetNT) ph_tp_second_fold(tid, kLDetNT, p, smem)) SYNC                     \
+    PHASE(if (tid < kLDetNT) ph_tp_finish(tid, kLDetNT, blk, p, smem))
 
 #define ECHO_CF_SEQUENCE(PHASE, SYNC, p, smem, pair, blk, nt)                      \
     PHASE(ph_cf_load(tid, nt, pair, blk, p, smem)) SYNC                             \

@@ -626,7 +626,7 @@ ECHO_HD void ph_ldet_finish(int tid, int blk, const LongParams& p, unsigned char
 // LDS: double pos[npos], then scratch double a[nt], double b[nt], int i[nt] (as doubles), then TpMisc.
 struct TpMisc { double best, amp, noise, best2; int ref, peak, nonzero, pad; };
 ECHO_HD double* tp_scratch(const LongParams& p, unsigned char* smem) {
-    return reinterpret_cast<double*>(smem + (((p.L - p.half) + 1) & ~1) * 8);
+    return reinterpret_cast<double*>(smem + p.det_lds_off);
 }
 ECHO_HD TpMisc* tp_misc(const LongParams& p, unsigned char* smem, int nt) {
     return reinterpret_cast<TpMisc*>(tp_scratch(p, smem) + 3 * nt);
@@ -648,6 +648,18 @@ ECHO_HD void ph_tp_load(int tid, int nt, int blk, const LongParams& p, unsigned 
         }
     }
     (void)npos;
+    double* sc = tp_scratch(p, smem);
+    sc[tid] = best; sc[nt + tid] = amp; reinterpret_cast<int*>(sc + 2 * nt)[tid] = bi;
+}
+// pass 1 where the correlation is in LDS already (LongParams::det_view): the same per-thread sequences as ph_tp_load
+ECHO_HD void ph_tp_scan_view(int tid, int nt, const LongParams& p, unsigned char* smem) {
+    double best = -INFINITY, amp = 0.0;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < p.L; k += nt) {
+        const double v = det_read(p, smem, k - p.half), av = fabs(v);
+        amp = av > amp ? av : amp;
+        if (k >= p.half && v > best) { best = v; bi = k - p.half; }
+    }
     double* sc = tp_scratch(p, smem);
     sc[tid] = best; sc[nt + tid] = amp; reinterpret_cast<int*>(sc + 2 * nt)[tid] = bi;
 }
@@ -676,12 +688,11 @@ ECHO_HD void ph_tp_ref(int tid, int nt, const LongParams& p, unsigned char* smem
 }
 // pass 2 over pos2: argmax, any nonzero, noise power
 ECHO_HD void ph_tp_second(int tid, int nt, const LongParams& p, unsigned char* smem) {
-    const double* pos = det_pos(smem);
     const TpMisc* m = tp_misc(p, smem, nt);
     const int npos = p.L - p.half, ref = m->ref;
     double best = -INFINITY, noise = 0.0; int bi = 0x7fffffff, nz = 0;
     for (int q = tid; q < npos; q += nt) {
-        const double v = q == ref ? 0.0 : pos[q];
+        const double v = q == ref ? 0.0 : det_read(p, smem, q);
         if (v > best) { best = v; bi = q; }
         nz |= (v != 0.0) ? 1 : 0;
         if (q < p.noise_n) noise += v * v;

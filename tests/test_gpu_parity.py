@@ -354,15 +354,16 @@ def test_original_variant_goldens_and_oracle(gold_original):
     e.close()
 
 
-def test_original_chain_detects_inside_the_matched_filter_kernel(gold_original, monkeypatch):
-    """airSonar.py parameters: the chain runs the matched filter and the median/MAD first crossing in one kernel (the
-    correlation stays in LDS).  Its records must be byte-identical to the two kernels with the correlation handed
-    over through memory (ECHO_FUSE_DET=0), on the golden frames and on synthetic ones -- among them frames of
-    silence, whose median and MAD are zero, and a frame count that is no multiple of anything."""
+@pytest.mark.parametrize("which", ["original", "twopeak"])
+def test_long_chain_detects_inside_the_matched_filter_kernel(which, monkeypatch):
+    """airSonar.py and 666.py parameters: the chain runs the matched filter and the detector (median/MAD first
+    crossing; two-peak) in one kernel, the correlation stays in LDS.  Its records must be byte-identical to the two
+    kernels with the correlation handed over through memory (ECHO_FUSE_DET=0) -- among the frames some of silence,
+    whose median and MAD are zero, and a frame count that is no multiple of anything."""
     from dsp_amd.engine import BatchedKalman
-    cfg = C.original_config()
+    cfg = C.original_config() if which == "original" else C.twopeak_config()
     t = build_tables(cfg)
-    rxs = np.concatenate([rx_from_i16(gold_original["rx_i16"]), synth_frames(157, cfg, t.tx_pcm)])
+    rxs = synth_frames(173, cfg, t.tx_pcm)
     rxs[5] = 0.0
     rxs[6, : cfg.n_rx // 2] = 0.0
     fused = _engine(cfg)
@@ -372,7 +373,7 @@ def test_original_chain_detects_inside_the_matched_filter_kernel(gold_original, 
     a, spec_a = fused.chain(rxs, n_streams=1, kalman=BatchedKalman(fused, 1), want_spectra=True)
     b, spec_b = apart.chain(rxs, n_streams=1, kalman=BatchedKalman(apart, 1), want_spectra=True)
     assert torch.equal(a, b) and torch.equal(spec_a, spec_b)
-    assert (_rec(a)["peak_idx"] >= 0).any()
+    assert _rec(a)["valid_mask"].any()
     fused.close(); apart.close()
 
 
