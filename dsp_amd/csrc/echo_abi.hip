@@ -51,6 +51,7 @@ struct EchoHandle {
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
     float2* d_uk = nullptr;
     cpx<float> *d_lroots = nullptr, *d_lwn = nullptr, *d_luk = nullptr;   // long path: spectrum FFT tables
+    cpx<float> *d_lbw = nullptr, *d_lbhat = nullptr;                       // long path, odd N: chirp factors and filter spectrum
     cpx<double> *d_cfg = nullptr, *d_cfw2 = nullptr, *d_cftw = nullptr;   // long path: FFT matched filter tables
     // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
     hipStream_t pf_stream = nullptr;
@@ -420,16 +421,17 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             rc = band_kernel_prepare(h->base.smem_bytes, h->base.spec_smem_bytes, h->base.spec_hilb_smem_bytes);
     } else if (rc == ECHO_OK) {
         if (h->lbase.has_spec) {
-            std::vector<cpx<float>> lr, lw, lu(h->lbase.n2 + 1);
-            gfft_tables(h->lbase.splan, lr, lw);
-            for (int k = 0; k <= h->lbase.n2; ++k) {
-                const double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)h->lbase.N;
-                lu[k] = cpx<float>{(float)std::cos(ang), (float)std::sin(ang)};
-            }
+            std::vector<cpx<float>> lr, lw, lu, lbw, lbh;
+            long_spec_tables(h->lbase, lr, lw, lu, lbw, lbh);
             up(dev_upload(&h->d_lroots, lr.data(), lr.size()));
             up(dev_upload(&h->d_lwn, lw.data(), lw.size()));
             up(dev_upload(&h->d_luk, lu.data(), lu.size()));
             h->lbase.sroots = h->d_lroots; h->lbase.swn = h->d_lwn; h->lbase.suk = h->d_luk;
+            if (h->lbase.spec_odd) {
+                up(dev_upload(&h->d_lbw, lbw.data(), lbw.size()));
+                up(dev_upload(&h->d_lbhat, lbh.data(), lbh.size()));
+                h->lbase.sbw = h->d_lbw; h->lbase.sbhat = h->d_lbhat;
+            }
         }
         if (const char* st = std::getenv("ECHO_DET_STAGES")) h->lbase.det_stages = std::atoi(st);   // development aids
         if (const char* st = std::getenv("ECHO_DET_PASSES")) h->lbase.det_passes = std::atoi(st);
@@ -481,7 +483,7 @@ void echo_destroy(EchoHandle* h) {
     for (hipEvent_t e : h->lane_kal) if (e) (void)hipEventDestroy(e);
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
-                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk,
+                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);

@@ -80,6 +80,16 @@ __global__ __launch_bounds__(kLSpecNT) void long_spec_kernel(LongParams p) {
     ph_lspec_store(tid, kLSpecNT, blk, p, smem, cur);
 }
 
+__global__ __launch_bounds__(kLSpecNT) void long_spec_odd_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_LSPEC_ODD_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kLSpecNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
 static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP; }
 
 int long_kernels_prepare(const LongParams& p) {
@@ -93,7 +103,7 @@ int long_kernels_prepare(const LongParams& p) {
                             p.tp_smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(long_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             p.lm_smem) != hipSuccess ||
-        (p.has_spec && hipFuncSetAttribute(reinterpret_cast<const void*>(long_spec_kernel),
+        (p.has_spec && hipFuncSetAttribute(reinterpret_cast<const void*>(p.spec_odd ? long_spec_odd_kernel : long_spec_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, p.spec_smem) != hipSuccess))
         return ECHO_ERR_HIP;
     return ECHO_OK;
@@ -122,6 +132,11 @@ int launch_long_corr(const LongParams& p, int B, hipStream_t s) {
 int launch_long_spec(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (!p.has_spec || !p.spec_in || !p.spec_out) return ECHO_ERR_UNSUPPORTED;
+    if (p.spec_odd) {
+        if (!p.sbw || !p.sbhat || p.sb_m < p.N + p.nbins - 1) return ECHO_ERR_INVALID;
+        hipLaunchKernelGGL(long_spec_odd_kernel, dim3(B * p.nb), dim3(kLSpecNT), p.spec_smem, s, p);
+        return ok();
+    }
     hipLaunchKernelGGL(long_spec_kernel, dim3(B * p.nb), dim3(kLSpecNT), p.spec_smem, s, p);
     return ok();
 }

@@ -103,6 +103,10 @@ struct LongParams {
     const cpx<float>* suk;           // global: n2 + 1, exp(-2*pi*i*k/N)
     const double* spec_in;           // [B][nb][N]
     float* spec_out;                 // [B][nb][nbins]
+    // odd N: no half-length packing exists; the N-point transform is a chirp-z (Bluestein) convolution of length sb_m
+    int spec_odd, sb_m;              // sb_m >= N + nbins - 1, a product of 2, 3, 5, 7 (splan is then the plan of sb_m)
+    const cpx<float>* sbw;           // global: N chirp factors w[n] = exp(-i pi n^2 / N)
+    const cpx<float>* sbhat;         // global: sb_m, DFT of the chirp filter conj(w) / sb_m
     int det_stages, det_passes;      // development aids: run only the first stages / passes of the detector (0 = all)
     int noise_n;                     // two-peak detector: length of the noise region of pos
     double snr_gate;
@@ -143,8 +147,20 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.tp_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + 64;
     p.lm_smem = ((npos + 1) & ~1) * 8 + 3 * kLDetNT * 8 + kLDetNT * 4 + 64;
     p.n2 = N / 2; p.nbins = N / 2 + 1;
-    p.has_spec = (N % 2 == 0) && gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
-    p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
+    p.spec_odd = N % 2; p.sb_m = 0;
+    if (!p.spec_odd) {
+        p.has_spec = gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
+        p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
+    } else {
+        // outputs 0 .. nbins-1 from inputs 0 .. N-1: the chirp filter is needed at -(N-1) .. nbins-1
+        p.has_spec = 0;
+        for (int m = N + p.nbins - 1; m <= 2 * N + 64 && !p.has_spec; ++m) {
+            int r = m;
+            for (int f = 2; f <= 7; ++f) while (r % f == 0) r /= f;
+            if (r == 1 && gfft_plan(p.splan, m, kLSpecNT)) { p.has_spec = 1; p.sb_m = m; }
+        }
+        p.spec_smem = 2 * p.sb_m * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
+    }
     if (p.spec_smem > 160 * 1024) p.has_spec = 0;
     return p.fir_smem <= 160 * 1024 && p.corr_smem <= 160 * 1024 && p.det_smem <= 160 * 1024 &&
            p.lm_smem <= 160 * 1024;
@@ -179,6 +195,97 @@ ECHO_HD void ph_lspec_store(int tid, int nt, int blk, const LongParams& p, unsig
         float mag = sqrtf(xr * xr + xi * xi);
         if (p.spec_db) mag = 20.0f * log10f(fmaxf(mag, 1e-12f));
         p.spec_out[(size_t)blk * p.nbins + k] = mag;
+    }
+}
+
+// Odd N (np.fft.rfft has no length restriction, airSonar_optimized.py:710): X[k] = w[k] sum_n (x[n] w[n]) conj(w)[k-n]
+// with w[n] = exp(-i pi n^2 / N), the sum as a cyclic convolution of length sb_m through the same mixed-radix FFT.
+// LDS: two buffers of sb_m complex floats, then the roots.
+ECHO_HD void ph_lspec_odd_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+    cpx<float>* z = reinterpret_cast<cpx<float>*>(smem);
+    const double* x = p.spec_in + (size_t)blk * p.N;
+    for (int n = tid; n < p.sb_m; n += nt) {
+        cpx<float> a{0.f, 0.f};
+        if (n < p.N) { const float v = (float)x[n]; const cpx<float> w = p.sbw[n]; a.x = v * w.x; a.y = v * w.y; }
+        z[n] = a;
+    }
+    cpx<float>* r = z + 2 * p.sb_m;
+    for (int i = tid; i < p.splan.nroots; i += nt) r[i] = p.sroots[i];
+}
+ECHO_HD void ph_lspec_odd_pass(int tid, int nt, const LongParams& p, unsigned char* smem, int ps, int src, bool inv) {
+    cpx<float>* b0 = reinterpret_cast<cpx<float>*>(smem);
+    const cpx<float>* r = b0 + 2 * p.sb_m + p.splan.root_off[ps];
+    gfft_pass<float>(tid, nt, p.splan, ps, b0 + (src ? p.sb_m : 0), b0 + (src ? 0 : p.sb_m), r, p.swn, inv);
+}
+ECHO_HD void ph_lspec_odd_mul(int tid, int nt, const LongParams& p, unsigned char* smem, int which) {
+    cpx<float>* z = reinterpret_cast<cpx<float>*>(smem) + (which ? p.sb_m : 0);
+    for (int k = tid; k < p.sb_m; k += nt) {
+        const cpx<float> a = z[k], b = p.sbhat[k];
+        z[k] = cpx<float>{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    }
+}
+ECHO_HD void ph_lspec_odd_store(int tid, int nt, int blk, const LongParams& p, unsigned char* smem, int which) {
+    const cpx<float>* y = reinterpret_cast<const cpx<float>*>(smem) + (which ? p.sb_m : 0);
+    for (int k = tid; k < p.nbins; k += nt) {
+        const cpx<float> a = y[k], w = p.sbw[k];
+        const float xr = a.x * w.x - a.y * w.y, xi = a.x * w.y + a.y * w.x;
+        float mag = sqrtf(xr * xr + xi * xi);
+        if (p.spec_db) mag = 20.0f * log10f(fmaxf(mag, 1e-12f));
+        p.spec_out[(size_t)blk * p.nbins + k] = mag;
+    }
+}
+#define ECHO_LSPEC_ODD_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                   \
+    do {                                                                                          \
+        PHASE(ph_lspec_odd_load(tid, nt, blk, p, smem)) SYNC                                      \
+        int cur_ = 0;                                                                             \
+        for (int ps_ = 0; ps_ < (p).splan.npass; ++ps_) {                                         \
+            PHASE(ph_lspec_odd_pass(tid, nt, p, smem, ps_, cur_, false)) SYNC                     \
+            cur_ ^= 1;                                                                            \
+        }                                                                                         \
+        PHASE(ph_lspec_odd_mul(tid, nt, p, smem, cur_)) SYNC                                      \
+        for (int ps_ = 0; ps_ < (p).splan.npass; ++ps_) {                                         \
+            PHASE(ph_lspec_odd_pass(tid, nt, p, smem, ps_, cur_, true)) SYNC                      \
+            cur_ ^= 1;                                                                            \
+        }                                                                                         \
+        PHASE(ph_lspec_odd_store(tid, nt, blk, p, smem, cur_))                                    \
+    } while (0)
+
+// Host: the tables of the long-frame spectrum.  Even N: roots, wn (length n2) and uk; odd N: roots, wn (length
+// sb_m), the chirp factors bw and the filter spectrum bhat (a direct O(sb_m^2) transform in double, once per handle).
+inline void long_spec_tables(const LongParams& p, std::vector<cpx<float>>& roots, std::vector<cpx<float>>& wn,
+                             std::vector<cpx<float>>& uk, std::vector<cpx<float>>& bw, std::vector<cpx<float>>& bhat) {
+    const double pi = 3.14159265358979323846;
+    gfft_tables(p.splan, roots, wn);
+    uk.assign((size_t)p.n2 + 1, cpx<float>{0.f, 0.f});
+    for (int k = 0; k <= p.n2; ++k) {
+        const double a = -2.0 * pi * (double)k / (double)p.N;
+        uk[k] = cpx<float>{(float)cos(a), (float)sin(a)};
+    }
+    bw.clear(); bhat.clear();
+    if (!p.spec_odd) return;
+    const int N = p.N, m = p.sb_m;
+    std::vector<double> wr(N), wi(N);
+    bw.resize(N);
+    for (int n = 0; n < N; ++n) {
+        const long long r = ((long long)n * n) % (2LL * N);     // n^2 mod 2N keeps the phase exact
+        const double a = -pi * (double)r / (double)N;
+        wr[n] = cos(a); wi[n] = sin(a);
+        bw[n] = cpx<float>{(float)wr[n], (float)wi[n]};
+    }
+    std::vector<double> br(m, 0.0), bi(m, 0.0), cr(m), ci(m);
+    for (int j = 0; j < p.nbins; ++j) { br[j] = wr[j]; bi[j] = -wi[j]; }
+    for (int j = 1; j < N; ++j) { br[m - j] = wr[j]; bi[m - j] = -wi[j]; }
+    for (int e = 0; e < m; ++e) { const double a = -2.0 * pi * (double)e / (double)m; cr[e] = cos(a); ci[e] = sin(a); }
+    bhat.resize(m);
+    for (int k = 0; k < m; ++k) {
+        double sr = 0.0, si = 0.0;
+        long long idx = 0;
+        for (int j = 0; j < m; ++j) {
+            sr += br[j] * cr[idx] - bi[j] * ci[idx];
+            si += br[j] * ci[idx] + bi[j] * cr[idx];
+            idx += k; if (idx >= m) idx -= m;
+        }
+        bhat[k] = cpx<float>{(float)(sr / m), (float)(si / m)};
     }
 }
 

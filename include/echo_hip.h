@@ -95,7 +95,9 @@ typedef struct EchoHandle EchoHandle;
 
 /* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
  * (airSonar_optimized.py:598-619).  Uses the current HIP device.
- * Sizes: the spectra need an even n_rx (odd frame lengths run everything else).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
+ * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution that must fit a
+ * workgroup's LDS (odd n_rx up to about 6600; beyond that the spectrum calls return ECHO_ERR_UNSUPPORTED and the chain
+ * runs with spec_db = NULL only).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
  * iir_ncoef = 1 with n_taps = 1 is the identity filter ([1], [1], [1]) design_filters falls back to (:178-182); zi may

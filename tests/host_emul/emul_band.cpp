@@ -327,13 +327,9 @@ extern "C" int emul_long_spec(int N, int M, int K, int nb, const double* band, i
     LongParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_long(p, N, M, K, nb, 0, 1) || !p.has_spec) return -2;
-    std::vector<cpx<float>> roots, wn, uk(p.n2 + 1);
-    gfft_tables(p.splan, roots, wn);
-    for (int k = 0; k <= p.n2; ++k) {
-        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;
-        uk[k] = cpx<float>{(float)std::cos(a), (float)std::sin(a)};
-    }
-    p.sroots = roots.data(); p.swn = wn.data(); p.suk = uk.data();
+    std::vector<cpx<float>> roots, wn, uk, bw, bhat;
+    long_spec_tables(p, roots, wn, uk, bw, bhat);
+    p.sroots = roots.data(); p.swn = wn.data(); p.suk = uk.data(); p.sbw = bw.data(); p.sbhat = bhat.data();
     p.spec_db = 1; p.spec_in = band; p.spec_out = spec_out;
     std::vector<unsigned char> smem(p.spec_smem);
     unsigned char* s = smem.data();
@@ -341,6 +337,12 @@ extern "C" int emul_long_spec(int N, int M, int K, int nb, const double* band, i
 #define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
     for (int blk = 0; blk < B * nb; ++blk) {
         std::memset(s, 0xff, smem.size());
+        if (p.spec_odd) {
+#define SYNC
+            ECHO_LSPEC_ODD_SEQUENCE(PHASE, SYNC, p, s, blk, nt);
+#undef SYNC
+            continue;
+        }
         PHASE(ph_lspec_load(tid, nt, blk, p, s));
         int cur = 0;
         for (int ps = 0; ps < p.splan.npass; ++ps) { PHASE(ph_lspec_pass(tid, nt, p, s, ps, cur)); cur ^= 1; }

@@ -192,9 +192,12 @@ def test_chain_with_other_frame_lengths_vs_oracle(kind, listen, chirp):
     e.close()
 
 
-def test_chain_with_odd_frame_length_without_spectra():
-    """An odd number of samples per frame (N = 4795): the spectrum kernels need an even N and refuse, everything else
-    of the chain runs (tiled kernels) and matches the oracle."""
+def test_chain_with_odd_frame_length():
+    """An odd number of samples per frame (N = 4795; np.fft.rfft has no length restriction, airSonar_optimized.py:710):
+    no half-length packing exists, the spectrum is a chirp-z convolution through the mixed-radix FFT; everything else of
+    the chain runs on the tiled kernels.  Against the oracle, spectra included, through the chain and through the
+    standalone entry point.  An odd frame too long for that convolution to fit a workgroup's LDS (N = 8821) still
+    runs without spectra and refuses them."""
     from dsp_amd._lib import EchoError
     from dataclasses import replace
     cfg = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=0.0999)
@@ -202,8 +205,22 @@ def test_chain_with_odd_frame_length_without_spectra():
     e = _engine(cfg)
     t = e.tables
     rx = synth_frames(40, cfg, t.tx_pcm, start=5)
+    exp = O.chain(rx, t.chirps_f32, t.filters, cfg, mode="named", keep=("spec_db", "band_sig"))
+    rec, spec = e.chain(rx, want_spectra=True)
+    check_records(_rec(rec), exp)
+    assert spec.shape == (40, cfg.n_bands, cfg.n_rx // 2 + 1)
+    check_spectra(spec.cpu().numpy(), exp["spec_db"])
+    band = torch.from_numpy(np.ascontiguousarray(exp["band_sig"])).to(e.device)
+    check_spectra(e.spectrum(band).cpu().numpy(), exp["spec_db"])
+    rec2, _ = e.chain(rx, want_spectra=False)
+    assert torch.equal(rec, rec2)
+    e.close()
+    cfg = replace(C.original_config(), LISTEN_LEN_FIXED=8821 / 44100 + 1e-7)
+    assert cfg.n_rx == 8821
+    e = _engine(cfg)
+    rx = synth_frames(8, cfg, e.tables.tx_pcm, start=5)
     rec, _ = e.chain(rx, want_spectra=False)
-    check_records(_rec(rec), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="named"))
+    check_records(_rec(rec), O.chain(rx, e.tables.chirps_f32, e.tables.filters, cfg, mode="named"))
     with pytest.raises(EchoError):
         e.chain(rx, want_spectra=True)
     e.close()

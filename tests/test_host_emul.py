@@ -134,6 +134,23 @@ def test_emulated_long_frame_path(emul, gold_original):
     assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
 
 
+def test_emulated_odd_length_spectrum(emul):
+    """rfft of an odd number of samples (N = 4795): chirp-z convolution through the mixed-radix FFT, thread by thread
+    on the host, against np.fft.rfft."""
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_long_spec.argtypes = [I, I, I, I, P, I, P]
+    rng = np.random.default_rng(2)
+    N, nb = 4795, 2
+    t = np.arange(N)
+    bs = rng.standard_normal((1, nb, N)) * 0.01 + 0.3 * np.sin(2 * np.pi * 0.0913 * t) + 0.1 * np.cos(2 * np.pi * 0.31 * t)
+    bs = np.ascontiguousarray(bs)
+    spec = np.zeros((1, nb, N // 2 + 1), np.float32)
+    assert emul.emul_long_spec(N, 275, 61, nb, _ptr(bs), 1, _ptr(spec)) == 0
+    ref = np.abs(np.fft.rfft(bs[0], axis=-1))
+    lin = 10 ** (spec[0].astype(np.float64) / 20)
+    assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
+
+
 def test_emulated_long_frame_detectors_against_oracle(emul):
     """The four detectors of the tiled long-frame path, thread by thread, on synthetic correlations (noise, one or two
     peaks, silence, ties, a peak inside the blind zone) against the oracle's first_strong_peak functions: indices
