@@ -762,10 +762,18 @@ ECHO_HD void ph_tp_load(int tid, int nt, int blk, const LongParams& p, unsigned 
 ECHO_HD void ph_tp_scan_view(int tid, int nt, const LongParams& p, unsigned char* smem) {
     double best = -INFINITY, amp = 0.0;
     int bi = 0x7fffffff;
-    for (int k = tid; k < p.L; k += nt) {
-        const double v = det_read(p, smem, k - p.half), av = fabs(v);
-        amp = av > amp ? av : amp;
-        if (k >= p.half && v > best) { best = v; bi = k - p.half; }
+    for (int k0 = tid; k0 < p.L; k0 += 4 * nt) {            // four LDS reads in flight; folded in ascending k
+        double v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = k0 + e * nt < p.L ? det_read(p, smem, k0 + e * nt - p.half) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e * nt;
+            if (k >= p.L) break;
+            const double v = v4[e], av = fabs(v);
+            amp = av > amp ? av : amp;
+            if (k >= p.half && v > best) { best = v; bi = k - p.half; }
+        }
     }
     double* sc = tp_scratch(p, smem);
     sc[tid] = best; sc[nt + tid] = amp; reinterpret_cast<int*>(sc + 2 * nt)[tid] = bi;
@@ -798,11 +806,19 @@ ECHO_HD void ph_tp_second(int tid, int nt, const LongParams& p, unsigned char* s
     const TpMisc* m = tp_misc(p, smem, nt);
     const int npos = p.L - p.half, ref = m->ref;
     double best = -INFINITY, noise = 0.0; int bi = 0x7fffffff, nz = 0;
-    for (int q = tid; q < npos; q += nt) {
-        const double v = q == ref ? 0.0 : det_read(p, smem, q);
-        if (v > best) { best = v; bi = q; }
-        nz |= (v != 0.0) ? 1 : 0;
-        if (q < p.noise_n) noise += v * v;
+    for (int q0 = tid; q0 < npos; q0 += 4 * nt) {           // four LDS reads in flight; folded in ascending q
+        double v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = q0 + e * nt < npos ? det_read(p, smem, q0 + e * nt) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = q0 + e * nt;
+            if (q >= npos) break;
+            const double v = q == ref ? 0.0 : v4[e];
+            if (v > best) { best = v; bi = q; }
+            nz |= (v != 0.0) ? 1 : 0;
+            if (q < p.noise_n) noise += v * v;
+        }
     }
     double* sc = tp_scratch(p, smem);
     int* si = reinterpret_cast<int*>(sc + 2 * nt);
