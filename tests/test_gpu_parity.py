@@ -394,12 +394,16 @@ def test_long_chain_detects_inside_the_matched_filter_kernel(which, monkeypatch)
     fused.close(); apart.close()
 
 
-def test_mad_detector_shortcut_and_general_selection_against_oracle():
+@pytest.mark.parametrize("n_rx", [8820, 8822])
+def test_mad_detector_shortcut_and_general_selection_against_oracle(n_rx):
     """first_strong_peak of airSonar.py (median/MAD first crossing, :104-117) on crafted correlations of the original
     parameter set's size.  Most frames take the kernel's shortcut (median of pos settled by counting the blind zone's
     zeros, MAD by one histogram); the others break one of its assumptions each and must come out of the general radix
-    selection with the same exact index."""
-    cfg = C.original_config()
+    selection with the same exact index.  N = 8822 makes len(pos) even: both medians are means of two order
+    statistics.  Then the chain (detector inside the matched-filter kernel) on synthetic frames against the oracle."""
+    from dataclasses import replace
+    cfg = replace(C.original_config(), LISTEN_LEN_FIXED=n_rx / 44100 + 1e-7)
+    assert cfg.n_rx == n_rx and (cfg.n_corr - cfg.half) % 2 == (1 if n_rx == 8820 else 0)
     e = _engine(cfg)
     rng = np.random.default_rng(5)
     nb, L, half = cfg.n_bands, cfg.n_corr, cfg.half
@@ -427,6 +431,10 @@ def test_mad_detector_shortcut_and_general_selection_against_oracle():
     peak, _, _ = e.first_strong_peak(torch.from_numpy(c.copy()).to(e.device))
     assert np.array_equal(peak.cpu().numpy(), want)
     assert (want >= 0).sum() >= 12 and (want < 0).any()
+    rx = synth_frames(48, cfg, e.tables.tx_pcm, start=31)
+    rx[3] = 0.0
+    rec, _ = e.chain(rx, want_spectra=False)
+    check_records(_rec(rec), O.chain(rx, e.tables.chirps_f32, e.tables.filters, cfg, mode="named"))
     e.close()
 
 
