@@ -297,10 +297,8 @@ struct Df2tQuad {
 // row_shl:1 with bound_ctrl hands every lane its neighbour's state and the last lane a zero; row_newbcast:0 spreads y.
 // Four times the instruction issue per frame of the quad mapping: only for batches that leave the chip idle anyway.
 __device__ __forceinline__ double dpp_row_bcast0(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150, 0xf, 0xf, false);   // row_newbcast:0 (every lane is written)
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    // row_newbcast:0 (every lane is written) is the one DPP control the float64 data path takes: one 64-bit move
+    return __builtin_amdgcn_update_dpp(v, v, 0x150, 0xf, 0xf, false);
 }
 __device__ __forceinline__ double dpp_row_next(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
