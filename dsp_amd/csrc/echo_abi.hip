@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -38,8 +39,26 @@ static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 constexpr int kMaxDevices = 64;
 static unsigned char* g_noalloc_ptr[kMaxDevices];          // per device: device address of `scratch`, null until looked up
 
+// Serialises the host side of the calls on one handle.  The reference calls its per-band functions from three pool
+// threads at once (airSonar_optimized.py:717-719); a handle's scratch, plans, prefetch and timing state change inside a
+// call, so every entry point that touches them holds this lock for its duration.  Recursive: echo_graph_create records an
+// echo_chain call.  Copying a handle (lane clones) gives the copy a lock of its own.
+struct HandleLock {
+    std::recursive_mutex m;
+    HandleLock() {}
+    HandleLock(const HandleLock&) {}
+    HandleLock& operator=(const HandleLock&) { return *this; }
+};
+#define ECHO_LOCK(h) std::lock_guard<std::recursive_mutex> echo_guard_((h)->lk.m)
+
 struct EchoHandle {
     EchoConfig cfg;
+    HandleLock lk;
+    // The handle's scratch serves one call at a time on the device too: a call issued on another stream than the call
+    // before it first makes its stream wait for everything queued on that earlier stream (order_scratch_use).
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
+    hipEvent_t xs_event = nullptr;
     int device = 0;
     bool bodd0 = false;
     BandParams base;                       // sizes, layout and device table pointers
@@ -102,6 +121,7 @@ struct EchoHandle {
     bool is_clone = false;
     int fuse_det = 1;                      // ECHO_FUSE_DET=0: matched filter and median/MAD detector of long frames as two kernels
     int self_lanes = 1;                    // ECHO_LANES=0: large calls run pass after pass on the caller's stream
+    bool lanes_ready = false;              // clones, streams and events of the lanes all exist
     EchoHandle* lane_clone[2] = {nullptr, nullptr};
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t lane_fork = nullptr, lane_join[3] = {nullptr, nullptr, nullptr}, lane_kal[3] = {nullptr, nullptr, nullptr};
@@ -299,6 +319,25 @@ bool on_device(const EchoHandle* h) {
     return h && hipGetDevice(&dev) == hipSuccess && dev == h->device;
 }
 
+// A call that uses the handle's scratch on stream s while work of an earlier call may still use it on another stream:
+// s waits for everything queued on that earlier stream so far (an event recorded there now covers the earlier call).
+// Nothing is done inside a stream capture, and nothing when the stream is the one of the call before.
+int order_scratch_use(EchoHandle* h, hipStream_t s) {
+    if (h->capturing) return ECHO_OK;
+    if (h->last_stream_set && h->last_stream != s) {
+        if (!h->xs_event && hipEventCreateWithFlags(&h->xs_event, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+        if (hipEventRecord(h->xs_event, h->last_stream) == hipSuccess) {
+            if (hipStreamWaitEvent(s, h->xs_event, 0) != hipSuccess) return ECHO_ERR_HIP;
+        } else {
+            // the earlier stream no longer exists; its work may still be running
+            (void)hipGetLastError();
+            if (hipDeviceSynchronize() != hipSuccess) return ECHO_ERR_HIP;
+        }
+    }
+    h->last_stream = s; h->last_stream_set = true;
+    return ECHO_OK;
+}
+
 bool detector_supported(const EchoHandle* h) {
     const int d = h->cfg.detector;
     return h->long_path ? (d >= ECHO_DET_MEDIAN && d <= ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
@@ -481,6 +520,7 @@ void echo_destroy(EchoHandle* h) {
     if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
     for (hipEvent_t e : h->lane_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->lane_kal) if (e) (void)hipEventDestroy(e);
+    if (h->xs_event) (void)hipEventDestroy(h->xs_event);
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
@@ -505,11 +545,13 @@ void echo_destroy(EchoHandle* h) {
 int echo_reserve(EchoHandle* h, int max_frames) {
     if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (!h || max_frames < 1) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
     return ensure_scratch(h, std::min(max_frames, h->max_chunk));
 }
 
 int echo_set_profiling_every(EchoHandle* h, int slots, int every) {
-    if (every < 1) return ECHO_ERR_INVALID;
+    if (every < 1 || !h) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
     const int rc = echo_set_profiling(h, slots);
     if (rc == ECHO_OK) h->prof_every = every;
     return rc;
@@ -517,6 +559,7 @@ int echo_set_profiling_every(EchoHandle* h, int slots, int every) {
 
 int echo_set_profiling(EchoHandle* h, int slots) {
     if (!h || slots < 0) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
     h->prof = slots > 0;
     h->prof_used = 0; h->prof_every = 1; h->prof_calls = 0;
     while ((int)h->ev.size() < kEvPerSlot * slots) {
@@ -529,7 +572,9 @@ int echo_set_profiling(EchoHandle* h, int slots) {
 }
 
 int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spec_ms, float* fuse_ms) {
-    if (!h || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
+    if (!h) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
+    if (!h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
     double acc[4] = {0, 0, 0, 0};
     for (int k = 0; k < h->prof_used; ++k) {
         hipEvent_t* e = &h->ev[kEvPerSlot * k];
@@ -550,7 +595,9 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
 }
 
 int echo_kernel_times(EchoHandle* h, float* ms, int n) {
-    if (!h || !ms || n < 1 || !h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
+    if (!h || !ms || n < 1) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
+    if (!h->prof || h->prof_used < 1) return ECHO_ERR_INVALID;
     double acc[6] = {0, 0, 0, 0, 0, 0};              // iir, band stage, spectrum, fusion, pair kernel, exact kernel
     int npair = 0;
     for (int k = 0; k < h->prof_used; ++k) {
@@ -597,6 +644,8 @@ int echo_bandpass_bank(EchoHandle* h, const float* rx, double* band_sig, int B, 
     if (h && B == 0) return ECHO_OK;                       // empty batch: nothing to do
     if (!h || !rx || !band_sig || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ECHO_LOCK(h);
+    if (int rc = order_scratch_use(h, s)) return rc;
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
         const int n = std::min(h->max_chunk, B - f0);
         int rc = ensure_scratch(h, n);
@@ -668,6 +717,8 @@ int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, doubl
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands;
+    ECHO_LOCK(h);
+    if (int rc = order_scratch_use(h, s)) return rc;
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
         const int n = std::min(h->max_chunk, B - f0);
         int rc = ensure_scratch(h, n);
@@ -699,6 +750,8 @@ int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope,
     if (!h->has_env) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands;
+    ECHO_LOCK(h);
+    if (int rc = order_scratch_use(h, s)) return rc;
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
         const int n = std::min(h->max_chunk, B - f0);
         int rc = ensure_scratch(h, n);
@@ -728,6 +781,8 @@ int echo_confidence_fuse(EchoHandle* h, const int32_t* peak_idx, const double* s
     if (!h || !peak_idx || !snr_db || !amplitude || !out || B < 0) return ECHO_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands;
+    ECHO_LOCK(h);
+    if (int rc = order_scratch_use(h, s)) return rc;
     for (int f0 = 0; f0 < B; f0 += h->max_chunk) {
         const int n = std::min(h->max_chunk, B - f0);
         int rc = ensure_scratch(h, n);
@@ -847,11 +902,14 @@ int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_windo
     if (h && rows == 0) return ECHO_OK;
     if (!h || !x || rows < 0 || len < 1 || min_delay < 0) return ECHO_ERR_INVALID;
     if (!on_device(h)) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
     if (h->capturing) return ECHO_ERR_INVALID;
     EnvParams* plan = nullptr;
     int rc = env_plan_for(h, len, smooth_window, &plan);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_scratch_use(h, s);
+    if (rc) return rc;
     const int step = 65535;
     const size_t need = (size_t)std::min(rows, step);
     if (need > h->env_rows_cap) {
@@ -875,7 +933,8 @@ int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_windo
 }
 
 // ext: scratch of a single pass provided by the caller of chain_impl (echo_chain_noalloc); null = the handle's own,
-// grown on demand.  With ext nothing is allocated, no prefetched IIR is consumed and no timing events are recorded.
+// grown on demand.  With ext nothing is allocated, a pending prefetched IIR is neither consumed nor discarded, and no
+// event of the handle's is recorded (the call may sit inside a stream capture of the caller's).
 static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, bool full,
                       double* quality, const Scratch* ext = nullptr, double* corr_out = nullptr,
@@ -930,7 +989,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         // the IIR result of this batch may already be on its way on the handle's own stream (echo_chain_prefetch)
         const bool pre = inner || (!ext && f0 == 0 && n == B && h->pf_valid && h->pf_rx == rx && h->pf_B == B);
         const double* y_in = sc.y;
-        if (f0 == 0 || inner) h->pf_valid = false;         // consumed or discarded
+        if (!ext && (f0 == 0 || inner)) h->pf_valid = false;   // consumed or discarded (a caller-scratch call leaves it alone)
         const int pre_slot = h->pf_slot;
         if (pre) {
             if (hipStreamWaitEvent(s, h->pf_ready[pre_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
@@ -1038,7 +1097,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             ++h->prof_used;
         }
     }
-    if (h->pf_stream && h->pf_gate && !h->capturing) {
+    if (!ext && h->pf_stream && h->pf_gate && !h->capturing) {
         h->chain_gen ^= 1;
         (void)hipEventRecord(h->chain_end[h->chain_gen], s);
         h->chain_end_set[h->chain_gen] = true;
@@ -1074,20 +1133,24 @@ static EchoHandle* clone_for_lane(const EchoHandle* h) {
     c->prof = false; c->ev.clear(); c->prof_pair.clear(); c->prof_slots = c->prof_used = 0;
     c->capturing = false; c->live_graphs = 0; c->self_lanes = 0;
     for (int i = 0; i < 3; ++i) { c->lane_stream[i] = nullptr; c->lane_join[i] = nullptr; c->lane_kal[i] = nullptr; }
-    c->lane_fork = nullptr;
+    c->lane_fork = nullptr; c->lanes_ready = false;
+    c->last_stream = nullptr; c->last_stream_set = false; c->xs_event = nullptr;
     return c;
 }
 
 static int ensure_lanes(EchoHandle* h) {
-    if (h->lane_stream[0]) return ECHO_OK;
+    if (h->lanes_ready) return ECHO_OK;
+    // every object is created only if it is still missing: a call that failed half-way is simply continued
     for (int i = 0; i < 2; ++i)
         if (!h->lane_clone[i] && !(h->lane_clone[i] = clone_for_lane(h))) return ECHO_ERR_NOMEM;
-    if (hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+    auto event = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    if (!event(h->lane_fork)) return ECHO_ERR_HIP;
     for (int i = 0; i < kSelfLanes; ++i)
-        if (hipEventCreateWithFlags(&h->lane_join[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->lane_kal[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
-    for (int i = kSelfLanes - 1; i >= 0; --i)              // stream 0 last: it is the mark that everything exists
-        if (hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
+        if (!event(h->lane_join[i]) || !event(h->lane_kal[i])) return ECHO_ERR_HIP;
+    for (int i = 0; i < kSelfLanes; ++i)
+        if (!h->lane_stream[i] && hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking) != hipSuccess)
+            return ECHO_ERR_HIP;
+    h->lanes_ready = true;
     return ECHO_OK;
 }
 
@@ -1095,6 +1158,11 @@ static int ensure_lanes(EchoHandle* h) {
 static int chain_entry(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x, double* kalman_p,
                        uint8_t* kalman_init, int B, int n_streams, void* stream, bool full, double* quality,
                        double* corr_out, hipEvent_t kal_wait, hipEvent_t kal_done) {
+    if (!h) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
+    if (on_device(h) && B > 0) {
+        if (int rc = order_scratch_use(h, static_cast<hipStream_t>(stream))) return rc;
+    }
     const bool kal = kalman_x || kalman_p || kalman_init;
     int chunk = (h && h->long_path) ? kLaneChunkLong : kLaneChunk;
     if (h && kal && n_streams >= 1 && n_streams <= chunk) chunk = (chunk / n_streams) * n_streams;
@@ -1131,13 +1199,21 @@ static int chain_entry(EchoHandle* h, const float* rx, EchoResult* out, float* s
         if (rc) break;
         if (kal) prev = done;
     }
-    // the caller's stream continues when every lane is through -- also after an error, so that nothing is left behind
+    // The caller's stream continues when every lane is through -- also after an error, so that nothing is left behind:
+    // every lane is joined whatever the others' joins return, and the first error of the call is the one reported.
+    int join_rc = ECHO_OK;
     for (int k = 0; k < kSelfLanes; ++k) {
         if (hipEventRecord(h->lane_join[k], h->lane_stream[k]) != hipSuccess ||
-            hipStreamWaitEvent(s, h->lane_join[k], 0) != hipSuccess) return ECHO_ERR_HIP;
+            hipStreamWaitEvent(s, h->lane_join[k], 0) != hipSuccess) {
+            // this lane cannot be ordered before the caller's stream by an event: wait for it here instead
+            (void)hipStreamSynchronize(h->lane_stream[k]);
+            if (join_rc == ECHO_OK) join_rc = ECHO_ERR_HIP;
+        }
     }
-    if (!rc && !kal && kal_done && hipEventRecord(kal_done, s) != hipSuccess) return ECHO_ERR_HIP;
-    return rc;
+    if (rc) return rc;
+    if (join_rc) return join_rc;
+    if (!kal && kal_done && hipEventRecord(kal_done, s) != hipSuccess) return ECHO_ERR_HIP;
+    return ECHO_OK;
 }
 
 int echo_chain_ordered(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* kalman_x,
@@ -1171,6 +1247,7 @@ int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* s
                        double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream) {
     if (!h || B < 0) return ECHO_ERR_INVALID;
     if (B == 0) return ECHO_OK;
+    ECHO_LOCK(h);
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != h->device || !h->noalloc) return ECHO_ERR_INVALID;
     if (B > h->max_chunk) return ECHO_ERR_TOO_LARGE;        // one internal pass only
@@ -1209,13 +1286,16 @@ int echo_chain_prefetch(EchoHandle* h, const float* rx, int B) {
     if (h && !on_device(h)) return ECHO_ERR_INVALID;         // the handle belongs to another device
     if (!h || !rx || B < 1) return ECHO_ERR_INVALID;
     if (B > h->max_chunk) return ECHO_ERR_UNSUPPORTED;
+    ECHO_LOCK(h);
     int rc = ensure_prefetch(h, B);
     if (rc) return rc;
     return issue_prefetch(h, rx, B, nullptr, true);
 }
 
 int echo_prefetch_ms(EchoHandle* h, float* iir_ms) {
-    if (!h || !iir_ms || !h->pf_timed) return ECHO_ERR_INVALID;
+    if (!h || !iir_ms) return ECHO_ERR_INVALID;
+    ECHO_LOCK(h);
+    if (!h->pf_timed) return ECHO_ERR_INVALID;
     if (hipEventSynchronize(h->pf_t1) != hipSuccess || hipEventElapsedTime(iir_ms, h->pf_t0, h->pf_t1) != hipSuccess)
         return ECHO_ERR_HIP;
     return ECHO_OK;
@@ -1231,6 +1311,7 @@ int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                       double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream, EchoGraph** graph) {
     if (!h || !graph || !stream || B < 1 || B > h->max_chunk || !on_device(h)) return ECHO_ERR_INVALID;
     *graph = nullptr;
+    ECHO_LOCK(h);
     int rc = ensure_scratch(h, B);          // allocate before the capture: nothing inside it may allocate
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1257,13 +1338,15 @@ int echo_graph_create(EchoHandle* h, const float* rx, EchoResult* out, float* sp
 }
 
 int echo_graph_launch(EchoGraph* g, void* stream) {
-    if (!g || !g->exec) return ECHO_ERR_INVALID;
+    if (!g || !g->exec || !g->owner) return ECHO_ERR_INVALID;
+    ECHO_LOCK(g->owner);                    // the recorded kernels use the owner's scratch
+    if (int rc = order_scratch_use(g->owner, static_cast<hipStream_t>(stream))) return rc;
     return hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
 }
 
 void echo_graph_destroy(EchoGraph* g) {
     if (!g) return;
-    if (g->owner) --g->owner->live_graphs;
+    if (g->owner) { ECHO_LOCK(g->owner); --g->owner->live_graphs; }
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

@@ -8,9 +8,15 @@ tensors in -> torch CUDA tensors out.  All arithmetic runs in the HIP library; a
 ``EchoError`` instead of reaching a kernel.
 
 A process-wide default engine is created lazily on the current GPU; ``use_engine`` swaps it.
+
+Threads: the reference submits its per-band functions from ``ThreadPoolExecutor(max_workers=3)``
+(airSonar_optimized.py:717-719), so every function here may be called from several threads at once.  The engine cache
+below is guarded by a lock, and the library serialises the calls on one handle itself (include/echo_hip.h, "Threads and
+streams"); each call works on arrays of its own, as in the reference.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import replace
 from typing import Optional
 
@@ -25,22 +31,28 @@ from .engine import BatchedKalman, EchoEngine, records_to_numpy
 
 _engine: Optional[EchoEngine] = None
 _filter_engines = {}          # engines for (b, a, taps) tuples that are not one of the default engine's bands
+_cache_lock = threading.RLock()   # guards the two caches above: three pool threads may arrive at a cold cache together
 
 
 def get_engine(cfg: Optional[SonarConfig] = None) -> EchoEngine:
     global _engine
-    if _engine is None or (cfg is not None and cfg != _engine.cfg):
-        use_engine(EchoEngine(cfg or optimized_config()))
-    return _engine
+    e = _engine
+    if e is not None and (cfg is None or cfg == e.cfg):
+        return e
+    with _cache_lock:
+        if _engine is None or (cfg is not None and cfg != _engine.cfg):
+            use_engine(EchoEngine(cfg or optimized_config()))
+        return _engine
 
 
 def use_engine(engine: EchoEngine):
     global _engine
-    if engine is not _engine:
-        for e in _filter_engines.values():
-            e.close()
-        _filter_engines.clear()
-    _engine = engine
+    with _cache_lock:
+        if engine is not _engine:
+            # dropped, not closed: another thread may be inside a call on one of them; an engine closes itself when
+            # the last reference to it goes
+            _filter_engines.clear()
+        _engine = engine
 
 
 def _is_np(x):
@@ -94,8 +106,11 @@ def _engine_for_filter(filt, e: EchoEngine) -> EchoEngine:
     design_filters falls back to (airSonar_optimized.py:178-182); anything else raises EchoError."""
     b, a, taps = (np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in filt)
     key = (b.tobytes(), a.tobytes(), taps.tobytes())
-    if key in _filter_engines:
-        return _filter_engines[key]
+    with _cache_lock:
+        return _filter_engines.get(key) or _make_filter_engine(key, b, a, taps, e)
+
+
+def _make_filter_engine(key, b, a, taps, e: EchoEngine) -> EchoEngine:
     na = max(len(a), len(b))
     bb = np.zeros(na); aa = np.zeros(na)
     bb[:len(b)] = b; aa[:len(a)] = a
@@ -108,8 +123,8 @@ def _engine_for_filter(filt, e: EchoEngine) -> EchoEngine:
     t0 = e.tables
     tables = SonarTables(cfg=cfg1, b=bb[None], a=aa[None], zi=zi[None], taps=taps[None], chirps=t0.chirps[:1],
                          tx_pcm=t0.tx_pcm, filters=[(b, a, taps)], chirps_f32=t0.chirps_f32[:1])
-    if len(_filter_engines) >= 8:                      # bounded cache
-        _filter_engines.pop(next(iter(_filter_engines))).close()
+    if len(_filter_engines) >= 8:                      # bounded cache; the evicted engine closes with its last user
+        _filter_engines.pop(next(iter(_filter_engines)))
     eng = EchoEngine(cfg1, e.device, tables=tables)
     _filter_engines[key] = eng
     return eng

@@ -348,6 +348,7 @@ class EchoEngine:
         """``count`` synthetic rx frames generated in device memory (frame g = a function of (seed, g)); float32
         [count, n_rx] on the int16 grid.  Same recipe as dsp_amd.synth with its own random stream."""
         if getattr(self, "_tx_mix_dev", None) is None:
+            # (two threads arriving here together both build the same array; the later assignment wins, either is valid)
             self._tx_mix_dev = torch.from_numpy((self.tables.tx_pcm.astype(np.float64) / 32768.0).astype(np.float32)
                                                 ).to(self.device)
         rx = (self._empty((count, self.cfg.n_rx), torch.float32) if out is None

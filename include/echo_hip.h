@@ -11,9 +11,23 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on it.
  *   - Return value: 0 on success, negative ECHO_ERR_* otherwise; echo_strerror() names it.  Data-dependent
  *     "no echo" is not an error: peak_idx = -1, snr_db = 0, valid = 0 (reference: `return None, 0.0`).
- *   - A handle is immutable after echo_create except for its grow-only scratch; use one handle per
- *     device and do not issue overlapping calls on the same handle from different streams.  A handle belongs to the
- *     device that was current in echo_create: calls with another device current return ECHO_ERR_INVALID.
+ *   - Threads and streams.  The tables of a handle are immutable after echo_create; everything else it owns changes
+ *     inside calls: the scratch grows on demand (hipFree + hipMalloc), envelope plans are made on first use, the
+ *     prefetch buffers, timing events and internal lanes come and go.  The reference calls its per-band functions from
+ *     three pool threads at once (airSonar_optimized.py:717-719), so every entry point that touches that state takes a
+ *     lock owned by the handle for the duration of the call: calls on one handle from several threads are serialised,
+ *     never interleaved, and need no lock of the caller's.  (echo_destroy is the exception: no other call on the handle
+ *     may be running or follow.)  On the device a handle's scratch serves one call at a time: calls issued on one
+ *     stream are ordered by it; a call on another stream than the previous call on that handle first makes its stream
+ *     wait for the work queued on the earlier one (one event, no host wait).  Calls on one handle therefore never
+ *     overlap on the device; to overlap batches use one handle per stream (echo_chain_ordered).  Inputs and outputs
+ *     belong to the caller: two calls that write the same output race as any two kernels would.
+ *     echo_chain_noalloc is outside this device-side ordering (its scratch is per GPU, not per handle; see there).
+ *   - A handle belongs to the device that was current in echo_create: calls with another device current return
+ *     ECHO_ERR_INVALID.
+ *   - Samples are finite numbers (AudioIO.record delivers int16 / 2**15, airSonar_optimized.py:573).  Frames holding
+ *     Inf or NaN are outside the contract: the zero-phase IIR then yields a different Inf/NaN pattern than
+ *     scipy.signal.filtfilt (it evaluates z + 0 * y where SciPy evaluates z alone).
  */
 #ifndef ECHO_HIP_H
 #define ECHO_HIP_H
@@ -244,8 +258,9 @@ int echo_chain_wave(EchoHandle* h, const float* rx, EchoResult* out, float* spec
  * ranges) lives in a file-scope device array of ECHO_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds
  * until the process ends.  B is limited to what fits: echo_noalloc_max_frames(h) (256 frames for the reference's
  * constants N = 4282, three bands, order 6); beyond it ECHO_ERR_TOO_LARGE and nothing runs.  The call never invokes
- * hipMalloc/hipFree, does not grow the handle's scratch, ignores a pending echo_chain_prefetch and records no timing
- * events.  It must be issued with the handle's device current.  Every call on a GPU shares that GPU's array: calls that
+ * hipMalloc/hipFree, does not grow the handle's scratch, leaves a pending echo_chain_prefetch pending (the next
+ * echo_chain with that rx still finds it) and records no event of the handle's, so it may be issued on a stream that is
+ * being captured into a HIP graph.  It must be issued with the handle's device current.  Every call on a GPU shares that GPU's array: calls that
  * overlap on one GPU (different streams or handles) race; calls on one stream are ordered and safe. */
 #define ECHO_NOALLOC_SCRATCH_BYTES (72u << 20)
 int echo_chain_noalloc(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
