@@ -67,3 +67,49 @@ def test_noalloc_chain_matches_chain_two_calls_in_a_row(which):
         e.chain_noalloc(big, out)
     assert lib.echo_chain_noalloc(h, _p(big), _p(out), None, None, None, None, 0, 1, stream) == 0     # empty batch
     e.close()
+
+
+def test_noalloc_chain_inside_a_stream_capture():
+    """echo_chain_noalloc between hipStreamBeginCapture and hipStreamEndCapture (torch's graph capture in its 'global'
+    error mode, where a hipMalloc or an un-captured event operation anywhere in the process fails the capture):
+    nothing executes while capturing, every replay leaves the bytes echo_chain leaves -- Kalman state carried from
+    replay to replay -- and a prefetch that was pending on the handle is still honoured afterwards."""
+    from dsp_amd import config as cfgs
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.synth import synth_frames
+    cfg = cfgs.optimized_config(cfgs.BANDS_DISTINCT)
+    e = EchoEngine(cfg)
+    lib, h = e.lib, e._h
+    B, S = 64, 8
+    pool = torch.from_numpy(synth_frames(3 * B, cfg, e.tables.tx_pcm, start=77)).to(e.device)
+    ticks = [pool[:B].contiguous(), pool[B:2 * B].contiguous()]
+    other = pool[2 * B:].contiguous()
+    k_ref, k_new = BatchedKalman(e, S), BatchedKalman(e, S)
+    want = []
+    for rx in ticks:
+        want.append(e.chain(rx, n_streams=S, kalman=k_ref))
+    want_other = e.chain(other)
+    torch.cuda.synchronize()
+    e.chain_prefetch(other)                                   # stays pending across the captured call
+    rx = torch.empty_like(ticks[0])
+    out = torch.full((B, 64), 0xAB, dtype=torch.uint8, device=e.device)
+    spec = torch.full((B, cfg.n_bands, cfg.n_bins), float("nan"), dtype=torch.float32, device=e.device)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=e.device)
+    with torch.cuda.graph(g, stream=side):
+        rc = lib.echo_chain_noalloc(h, _p(rx), _p(out), _p(spec), _p(k_new.x), _p(k_new.p), _p(k_new.init), B, S,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.echo_strerror(rc)
+    torch.cuda.synchronize()
+    assert bool((out == 0xAB).all())                          # recorded, not run
+    for t, frames in enumerate(ticks):
+        rx.copy_(frames)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want[t][0]) and torch.equal(spec, want[t][1]), t
+    assert torch.equal(k_ref.x, k_new.x) and torch.equal(k_ref.p, k_new.p) and torch.equal(k_ref.init, k_new.init)
+    got_other = e.chain(other)
+    torch.cuda.synchronize()
+    assert torch.equal(got_other[0], want_other[0]) and torch.equal(got_other[1], want_other[1])
+    del g
+    e.close()
