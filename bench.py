@@ -179,7 +179,7 @@ def main():
     import torch.distributed as dist
 
     from dsp_amd.config import optimized_config, original_config, realtime_config, twopeak_config
-    from dsp_amd.dist import shard_bounds
+    from dsp_amd.dist import GatherRing, shard_bounds
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.lanes import ChainLanes
     from dsp_amd.synth import synth_frames
@@ -231,67 +231,51 @@ def main():
             lanes.submit(rx[:warm.shape[0]], want_spectra=False, out=warm, mode=args.mode)
         lanes.join()
         torch.cuda.synchronize(dev)
+    want_spec = not args.no_spectra
+    if lanes is None and use_dist and not args.no_pipeline and not strong and B <= 4096:
+        # one stream with the next step's IIR prefetched: the engine's prefetch stream likewise takes its hardware queue
+        # (one small prefetched batch) before the collective library creates its streams
+        warm_rx = rx[:min(B, 64)].contiguous()
+        eng.chain_prefetch(warm_rx)
+        eng.chain(warm_rx, want_spectra=False)
+        torch.cuda.synchronize(dev)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-    want_spec = not args.no_spectra
-    # Output buffers, one set per lane (at least two): with several ranks the all-gather of step k is asynchronous and
-    # only has to be complete before the step that writes the same buffer again, so the collective never stalls the
-    # compute streams.  Uneven shards are padded to the largest one inside the buffer the collective sends.
+    # Output buffers, one set per lane (at least two), and the exchange of the records (dsp_amd.dist.GatherRing): with
+    # several ranks the all-gather of step k is asynchronous and only has to be complete before the step that writes the
+    # same buffer again; with lanes it is issued from the batch's own lane, n_lanes - 1 steps later.  Uneven shards are
+    # padded to the largest one inside the buffer the collective sends.
     nbuf = max(2, n_lanes) if not strong else 2
-    send = [torch.zeros((Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    recs = [b[:B] for b in send]
+    ring = GatherRing(counts, rank, dev, nbuf=nbuf, delay=n_lanes if lanes is not None else 1, collective=use_dist)
+    recs = ring.recs
     nspec = 1 if (strong or n_lanes == 1) else nbuf         # the sharded job's spectra are one array per rank
     specs = [torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device=dev) if want_spec else None
              for _ in range(nspec)]
-    gathered = [torch.empty((world * Bmax, 64), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if use_dist else None
-    works = [None] * nbuf
-    counter = [0]
     pipeline = (lanes is None and not args.no_pipeline and not strong
                 and B <= (16384 if args.workload in ("optimized", "realtime") else 4096))
 
-    owed = []                                               # (buffer, lane stream) of batches not gathered yet
-
-    def gather_one():
-        b, st = owed.pop(0)
-        with torch.cuda.stream(st):
-            works[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
-
-    def step():
-        buf = counter[0] % nbuf
-        counter[0] += 1
-        if works[buf] is not None:
-            works[buf].wait()
+    def step(want_event=False):
+        buf = ring.acquire()                                # this buffer's previous gather is waited for (stream order)
         spec = specs[buf % nspec]
         if lanes is not None:
-            # rx is resident and never rewritten; the buffers of this slot are free once works[buf] has been waited for,
-            # which the lane has to see only when there is a collective
-            lanes.submit(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode,
-                         inputs_ready=not use_dist)
-            if use_dist:
-                # The gather of a batch is issued from the batch's own lane, n_lanes - 1 steps later (the rest at the
-                # fence): by then every lane's newer work is queued behind work that cannot start before this batch is
-                # done anyway, so the collective's wait for the batch -- its stream shares one of the few hardware
-                # queues with some lane -- holds nothing back.
-                owed.append((buf, lanes.last_stream))
-                if len(owed) >= n_lanes:
-                    gather_one()
-            return
+            # rx is resident and never rewritten; the buffers of this slot are free once their gather has been waited
+            # for, which the lane has to see only when there is a collective
+            ev = lanes.submit(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec,
+                              mode=args.mode, inputs_ready=not use_dist, want_event=want_event)
+            ring.commit(buf, lanes.last_stream)
+            return ev
         eng.chain(rx, n_streams=S, kalman=kal, want_spectra=want_spec, out=recs[buf], spec_out=spec, mode=args.mode)
         if pipeline:
             eng.chain_prefetch(rx)
-        if use_dist:
-            works[buf] = dist.all_gather_into_tensor(gathered[buf], send[buf], async_op=True)
+        ring.commit(buf)
+        return None
 
     def fence():
-        while owed:
-            gather_one()
+        ring.flush()
         if lanes is not None:
             lanes.join()
-        for w in works:
-            if w is not None:
-                w.wait()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -330,6 +314,19 @@ def main():
         torch.cuda.synchronize(dev)
         kms_serial = eng.last_kernel_ms()
         eng.set_profiling(0)
+    steady = None
+    if lanes is not None and not strong and not use_dist:
+        # Beside the fenced wall-clock value, never instead of it: the rate between the completion of two batches of
+        # one continuous run, so that neither the filling nor the draining of the lanes is inside the interval.
+        n_ss = max(args.steps, 2 * n_lanes)
+        marks = (n_lanes - 1, n_lanes - 1 + n_ss)          # only these two batches carry a (timing) event
+        evs = [step(want_event=i in marks) for i in range(n_ss + 2 * n_lanes)]
+        fence()
+        ms_ss = evs[marks[0]].elapsed_time(evs[marks[1]])
+        steady = {"value": B * n_ss / (ms_ss / 1e3), "unit": "frames/s", "steps": n_ss, "ms_per_step": ms_ss / n_ss,
+                  "note": f"GPU events at the completion of batch {n_lanes} and batch {n_lanes + n_ss} of one run of "
+                          f"{n_ss + 2 * n_lanes} batches after the timed region, lanes neither filling nor draining "
+                          "inside the interval; `value` above is the fenced wall-clock figure"}
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -361,24 +358,39 @@ def main():
         if args.workload in ("original", "twopeak"):
             names.update({"band": "long-frame band stage (FIR + matched filter + detector kernels)"})
         dom_s = cand[dom] / 1e3
-        achieved = bytes_per_frame * launch_frames / dom_s / 1e9
-        traffic = None
+        tinfo = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_kernels.json")
         if os.path.exists(tpath) and args.workload == "optimized" and args.mode == "named" and launch_frames == FRAMES_PER_STEP:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch", {}).get(dom)
+                tinfo = json.load(open(tpath))
             except Exception:
-                traffic = None
+                tinfo = {}
+        per_kernel_traffic = tinfo.get("hbm_bytes_per_launch", {})
         wl = (f"configs[2]: {args.total_frames} distinct synthetic rx frames (generated on the devices) sharded over "
               f"{world} GPU(s), one pass per step, " if strong else
               (f"configs[1]: " if args.workload == "optimized" else f"variant '{args.workload}': ")
               + f"{B} synthetic rx frames per GPU per step, ")
+        # Top-level roofline: the algorithmic bytes the job moved per second of the timed region (value x bytes per
+        # frame) -- the figure tied to the same clock as `value`.  The per-kernel prices of one launch sit beside it:
+        # `dominant_kernel_alone` (the longest kernel with the GPU to itself) and `as_benched` (the longest kernel as it
+        # ran in the timed region, stretched by whatever ran beside it).
+        job_gbps = bytes_per_frame * frames / dt / 1e9 / world      # per GPU
+        as_benched = {"kernel": names[dom], "kernel_ms": cand[dom],
+                      "achieved": bytes_per_frame * launch_frames / dom_s / 1e9,
+                      "frac": bytes_per_frame * launch_frames / dom_s / 1e9 / HBM_PEAK_GBPS,
+                      "traffic": per_kernel_traffic.get(dom),
+                      "note": "algorithmic bytes of one launch over this kernel's event-measured duration inside the "
+                              "timed region"
+                              + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")
+                              + (f"; {n_lanes} batches are in flight, so the duration (first lane's calls, every eighth "
+                                 "timed) includes the time the kernel shares the GPU with the other lanes' kernels and can "
+                                 "exceed ms_per_step" if lanes is not None else "")}
         out = {
             "metric": "echo frames/sec (3-band filter+rfft+peak)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 (IIR, detector, fusion, Kalman) + f32 (FIR, FFT matched filter, spectrum)",
             "data": "synthetic (generated on the device)" if (args.device_synth or strong) else "synthetic",
             "config": {"workload": wl + f"{cfg.n_bands} bands, N={cfg.n_rx}, "
                                    f"M={cfg.n_chirp}, IIR order {cfg.IIR_ORDER} (filtfilt) + FIR {cfg.FIR_TAPS}, "
@@ -393,18 +405,17 @@ def main():
                                       "streams of its own)" if strong else ""),
                        "frames_per_gpu_per_step": B, "n_streams": S, "spectra": want_spec, "chain_mode": args.mode,
                        "pipelined_iir": pipeline, "lanes": n_lanes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": names[dom], "kernel_ms": cand[dom], "frames_per_launch": launch_frames,
+            "roofline": {"bound": "hbm", "achieved": job_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": job_gbps / HBM_PEAK_GBPS,
+                         "traffic": tinfo.get("total_bytes_per_4096_frames"),
+                         "basis": "whole job, per GPU: value x algorithmic bytes per frame / n_gpus",
+                         "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": launch_frames,
                          "algorithmic_bytes_per_launch": bytes_per_frame * launch_frames,
-                         "note": "algorithmic bytes of the whole chain (rx in, spectra + record out) over the longest "
-                                 "kernel's duration; the chain is bound by vector instruction issue and LDS "
-                                 "(~13 MFLOP/frame), so the HBM fraction is low by construction"
-                                 + ("; the IIR runs on the engine's stream beside the other kernels" if pipeline else "")
-                                 + (f"; {n_lanes} batches are in flight, so this kernel's duration (first lane's calls, "
-                                    "every eighth timed) is stretched by the other lanes' kernels running beside it "
-                                    "and exceeds ms_per_step: 'unshared' prices the same launch at the duration the "
-                                    "kernel has with the GPU to itself" if lanes is not None else "")},
+                         "note": "algorithmic bytes (rx in, spectra + record out) per second of the timed region; "
+                                 "`traffic` = HBM bytes all kernels of one 4096-frame step move (PMC counters). The "
+                                 "chain is bound by vector instruction issue, LDS and the IIR's latency "
+                                 "(~13 MFLOP/frame), so the HBM fraction is low by construction",
+                         "as_benched": as_benched},
             "kernel_ms": kms,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
         }
@@ -416,12 +427,12 @@ def main():
                 cs["band"] = kms_serial["band"]
             ds = max(cs, key=cs.get)
             a2 = bytes_per_frame * launch_frames / (cs[ds] / 1e3) / 1e9
-            out["roofline"]["unshared"] = {"kernel": names[ds], "kernel_ms": cs[ds], "achieved": a2,
-                                           "frac": a2 / HBM_PEAK_GBPS, "kernel_ms_all": kms_serial,
-                                           "note": "measured after the timed region: 6 calls on one stream, nothing overlapped"}
-            out["roofline"]["whole_chain"] = {"achieved": bytes_per_frame * frames / dt / 1e9,
-                                              "frac": bytes_per_frame * frames / dt / 1e9 / HBM_PEAK_GBPS,
-                                              "note": "algorithmic bytes per second of the whole job (value x bytes per frame)"}
+            out["roofline"]["dominant_kernel_alone"] = {
+                "kernel": names[ds], "kernel_ms": cs[ds], "achieved": a2, "frac": a2 / HBM_PEAK_GBPS,
+                "traffic": per_kernel_traffic.get(ds), "kernel_ms_all": kms_serial,
+                "note": "measured after the timed region: 6 calls on one stream, nothing overlapped"}
+        if steady is not None:
+            out["steady_state"] = steady
         if strong:
             out["config"]["total_frames"] = args.total_frames
             out["config"]["frames_per_rank"] = counts
@@ -442,9 +453,9 @@ def main():
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:
-        last = (counter[0] - 1) % nbuf
-        off = rank * Bmax
-        assert torch.equal(gathered[last][off:off + B], recs[last])   # the gathered records hold this rank's shard
+        last = ring.step_of.index(max(ring.step_of))
+        assert torch.equal(ring.own_rows(last), recs[last])           # the gathered records hold this rank's shard
+        assert ring.result(last).shape[0] == sum(counts)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -19,6 +19,7 @@ EXPORTS = [
     "echo_set_profiling", "echo_last_kernel_ms", "echo_chain_noalloc", "echo_noalloc_max_frames",
     "echo_spectrum_rows", "echo_xcorr", "echo_envelope_rows", "echo_band_confidence", "echo_normalize_confidences",
     "echo_kalman_update_qr", "echo_chain_wave", "echo_kernel_times", "echo_chain_ordered", "echo_set_profiling_every",
+    "echo_first_strong_peak_rows", "echo_spectrum_any",
 ]
 
 
@@ -71,6 +72,8 @@ def load():
     lib.echo_chain.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_spectrum_rows.argtypes = [P, P, P, I, I, P]
     lib.echo_xcorr.argtypes = [P, P, P, I, I, I, P]
+    lib.echo_first_strong_peak_rows.argtypes = [P, I, I, I, I, C.c_double, P, P, P]
+    lib.echo_spectrum_any.argtypes = [P, P, I, I, I, P]
     lib.echo_envelope_rows.argtypes = [P, P, I, I, I, P, P, P, P, P, P, I, P]
     lib.echo_band_confidence.argtypes = [P, P, P, P, P, I, P]
     lib.echo_normalize_confidences.argtypes = [P, P, I, I, P]

@@ -64,7 +64,7 @@ struct EchoHandle {
     BandParams base;                       // sizes, layout and device table pointers
     bool has_env = false;                  // envelope branch available (even correlation length with small prime factors)
     EnvParams ebase;
-    cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr;
+    cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr, *d_ebsw = nullptr, *d_ebsb = nullptr;
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
@@ -247,12 +247,12 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, dou
 
 int ensure_prefetch(EchoHandle* h, int frames) {
     if (!h->pf_stream) {
-        // A high-priority stream: it gets a hardware queue of its own (streams of equal priority share a small pool of
-        // queues round-robin, and a queue shared with the caller's stream would serialise the two), and the few
-        // long-running IIR wavefronts are placed ahead of the bulk kernels they run beside.
-        int prio_low = 0, prio_high = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        if (hipStreamCreateWithPriority(&h->pf_stream, hipStreamNonBlocking, prio_high) != hipSuccess) return ECHO_ERR_HIP;
+        // Default priority on purpose.  A high-priority stream kept a hardware queue of its own even beside the
+        // collective library's streams, but a process that also runs RCCL collectives then stopped making progress: the
+        // prefetched IIR waits (in its high-priority queue) for events of the caller's normal-priority stream, which in
+        // turn waits for a collective queued at normal priority, and that collective was never scheduled.  Callers that
+        // want the prefetch stream on a queue of its own issue their first prefetch before they initialise RCCL.
+        if (hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&h->pf_ready[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->pf_consumed[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
@@ -495,6 +495,15 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         up(dev_upload(&h->d_eroots, er.data(), er.size()));
         up(dev_upload(&h->d_ewn, ewn.data(), ewn.size()));
         up(dev_upload(&h->d_ewl, ewl.data(), ewl.size()));
+        if (h->ebase.bs_m) {
+            // half the correlation length has a prime factor beyond the mixed-radix passes (e.g. L = 4562 = 2 * 2281):
+            // the Hilbert transform's half-length FFTs run as Bluestein convolutions, as in echo_envelope_rows
+            std::vector<cpx<double>> bw, bb;
+            env_bs_tables(h->ebase, bw, bb);
+            up(dev_upload(&h->d_ebsw, bw.data(), bw.size()));
+            up(dev_upload(&h->d_ebsb, bb.data(), bb.size()));
+            h->ebase.bs_w = h->d_ebsw; h->ebase.bs_bhat = h->d_ebsb;
+        }
         if (rc == ECHO_OK) rc = env_kernel_prepare(h->ebase);
         if (const char* st = std::getenv("ECHO_ENV_STOP")) h->ebase.stop_after = std::atoi(st);   // development aid
         h->ebase.roots = h->d_eroots; h->ebase.wn = h->d_ewn; h->ebase.wl = h->d_ewl;
@@ -523,7 +532,7 @@ void echo_destroy(EchoHandle* h) {
     if (h->xs_event) (void)hipEventDestroy(h->xs_event);
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
-                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
+                    h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -863,6 +872,81 @@ int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int 
         if (rc) return rc;
     }
     return ECHO_OK;
+}
+
+int echo_first_strong_peak_rows(double* corr, int rows, int len, int min_delay, int noise_n, double snr_gate_db,
+                                int32_t* peak_idx, double* snr_db, void* stream) {
+    if (rows == 0) return ECHO_OK;
+    if (!corr || !peak_idx || !snr_db || rows < 0 || len < 1 || min_delay < 0 || noise_n < 0) return ECHO_ERR_INVALID;
+    const int rc = launch_fsp_rows(corr, rows, len, min_delay, noise_n, snr_gate_db, peak_idx, snr_db,
+                                   static_cast<hipStream_t>(stream));
+    return rc == 0 ? ECHO_OK : (rc == -2 ? ECHO_ERR_UNSUPPORTED : ECHO_ERR_HIP);
+}
+
+// ---- spectra of signals of any length.  A length the FFT kernels hold gets a plan of its own -- a one-band handle with
+// the identity filter, of which only the spectrum tables are used -- kept per (device, length); any other length runs
+// as direct sums against a table of its n roots of unity.  Plans live until the process ends (at most kSpecPlans of
+// them; the oldest goes first).
+namespace {
+struct SpecPlan { int device = -1, n = 0; EchoHandle* h = nullptr; double2* roots = nullptr; };
+constexpr int kSpecPlans = 16;
+constexpr int kSpecDftMax = 1 << 18;                        // direct sums: n^2 / 2 complex multiply-adds per row
+std::mutex g_spec_mu;
+std::vector<SpecPlan> g_spec_plans;
+
+int spec_plan_for(int n, SpecPlan** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return ECHO_ERR_NODEVICE;
+    for (auto& pl : g_spec_plans)
+        if (pl.device == dev && pl.n == n) { *out = &pl; return ECHO_OK; }
+    SpecPlan pl;
+    pl.device = dev; pl.n = n;
+    if (n >= 64) {
+        const double one = 1.0;
+        EchoConfig c;
+        std::memset(&c, 0, sizeof(c));
+        c.fs = 48000; c.n_rx = n; c.n_chirp = 1; c.n_bands = 1; c.iir_ncoef = 1; c.n_taps = 1; c.noise_n = 1;
+        c.detector = ECHO_DET_MEDIAN; c.snr_gate_db = 6.0; c.sound_speed = 343.0; c.kalman_q = 0.005; c.kalman_r = 0.1;
+        c.b = &one; c.a = &one; c.zi = nullptr; c.taps = &one; c.chirps = &one;
+        EchoHandle* h = nullptr;
+        if (echo_create(&c, &h) == ECHO_OK) {
+            if (h->long_path && !h->lbase.has_spec) { echo_destroy(h); h = nullptr; }
+            pl.h = h;
+        }
+    }
+    if (!pl.h) {
+        if (n > kSpecDftMax) return ECHO_ERR_UNSUPPORTED;
+        std::vector<double2> w((size_t)n);
+        const long double tau = 6.283185307179586476925286766559005768L;
+        for (int t = 0; t < n; ++t) {
+            const long double a = -tau * (long double)t / (long double)n;
+            w[t] = double2{(double)cosl(a), (double)sinl(a)};
+        }
+        const int rc = dev_upload(&pl.roots, w.data(), w.size());
+        if (rc) { (void)hipFree(pl.roots); return rc; }
+    }
+    if ((int)g_spec_plans.size() >= kSpecPlans) {
+        SpecPlan old = g_spec_plans.front();
+        g_spec_plans.erase(g_spec_plans.begin());
+        if (old.h) echo_destroy(old.h);                     // (hipFree inside waits for work still using the tables)
+        (void)hipFree(old.roots);
+    }
+    g_spec_plans.push_back(pl);
+    *out = &g_spec_plans.back();
+    return ECHO_OK;
+}
+}  // namespace
+
+int echo_spectrum_any(const double* x, float* spec, int db, int rows, int n, void* stream) {
+    if (rows == 0) return ECHO_OK;
+    if (!x || !spec || rows < 0 || n < 1) return ECHO_ERR_INVALID;
+    std::lock_guard<std::mutex> guard(g_spec_mu);
+    SpecPlan* pl = nullptr;
+    int rc = spec_plan_for(n, &pl);
+    if (rc) return rc;
+    if (pl->h) return echo_spectrum_rows(pl->h, x, spec, db, rows, stream);
+    rc = launch_dft_rows(x, pl->roots, spec, db, rows, n, static_cast<hipStream_t>(stream));
+    return rc == 0 ? ECHO_OK : ECHO_ERR_HIP;
 }
 
 // plan (and device tables) of the envelope kernel for rows of `len` samples smoothed over `smooth`, made once

@@ -80,5 +80,10 @@ int launch_band_confidence(const double* snr, const double* amp, const int32_t* 
 int launch_normalize_conf(const double* conf, double* out, int rows, int n, hipStream_t s);
 int launch_iir_order0(const float* rx, double* y, const double* b, int B, int N, int nb, hipStream_t s);
 int launch_xcorr(const double* a, const double* b, double* out, int rows, int n, int m, hipStream_t s);   // -2: b too long for LDS
+// rows_kernel.hip: per-row kernels for signals of any length.  Return 0, -2 (does not fit) or -4 (launch failed).
+int launch_fsp_rows(double* corr, int rows, int len, int min_delay, int noise_n, double gate_db, int32_t* peak_idx,
+                    double* snr_db, hipStream_t s);
+int launch_dft_rows(const double* x, const void* roots /* double2[n]: exp(-2 pi i t / n) */, float* spec, int db, int rows,
+                    int n, hipStream_t s);
 
 }  // namespace echo

@@ -9,6 +9,7 @@ produced them.  Sharding rules:
 """
 from __future__ import annotations
 
+from contextlib import nullcontext
 from typing import List, Optional, Tuple
 
 import torch
@@ -110,3 +111,95 @@ def process_sharded(engine, rx_global: torch.Tensor, n_streams: Optional[int] = 
         rec, spec = torch.empty((0, 64), dtype=torch.uint8, device=rx_global.device), None
     counts = [b - a for a, b in shard_bounds(rx_global.shape[0], world)]
     return gather_records(rec, counts, group), spec
+
+
+class GatherRing:
+    """The record exchange of a steady-state multi-rank loop: step k writes this rank's records into buffer
+    k % nbuf, and the all-gather of a step is asynchronous -- it only has to be complete before the step that writes
+    the same buffer again, so the collective never stalls the compute streams.
+
+    * Uneven shards (``counts`` = rows per rank) are padded to the largest one inside the buffer the collective sends;
+      ``result`` drops the padding again.
+    * ``delay``: the gather of a step is issued when ``delay - 1`` later steps have been committed (the rest at
+      ``flush``), from the stream the step itself was queued on.  With several batches in flight on several streams
+      (``ChainLanes``) ``delay`` = the number of lanes: by then every lane's newer work sits behind work that cannot start
+      before this batch is done anyway, so the collective's wait for the batch -- its stream shares one of the few
+      hardware queues with some lane -- holds nothing back.  ``nbuf >= delay`` keeps a buffer from coming round before
+      its gather has been issued.
+    * Without a process group (one rank, no collective) the ring only rotates the buffers.
+
+    Per step: ``buf = ring.acquire()``; queue the work that writes ``ring.recs[buf]`` (ordered after the caller's
+    current stream, which ``acquire`` made wait for the buffer's previous gather); ``ring.commit(buf, stream)``.
+    """
+
+    def __init__(self, counts: List[int], rank: int, device, nbuf: int = 2, delay: int = 1, group=None,
+                 width: int = 64, dtype=torch.uint8, collective: Optional[bool] = None):
+        if nbuf < 1 or delay < 1 or nbuf < delay:
+            raise ValueError("GatherRing: need nbuf >= delay >= 1")
+        self.counts = list(counts)
+        self.world, self.rank, self.group = len(self.counts), rank, group
+        self.rows, self.rows_max = self.counts[rank], max(self.counts)
+        self.nbuf, self.delay = nbuf, delay
+        self.collective = (dist.is_initialized() if collective is None else collective)
+        self.send = [torch.zeros((self.rows_max, width), dtype=dtype, device=device) for _ in range(nbuf)]
+        self.recs = [b[: self.rows] for b in self.send]           # what a step writes: this rank's rows
+        self.gathered = ([torch.empty((self.world * self.rows_max, width), dtype=dtype, device=device)
+                          for _ in range(nbuf)] if self.collective else None)
+        self._works = [None] * nbuf
+        self._owed: List[Tuple[int, object]] = []                  # committed, gather not issued yet: (buffer, stream)
+        self._steps = 0
+        self.step_of = [-1] * nbuf                                 # which step's records each buffer holds
+
+    def acquire(self) -> int:
+        """The buffer of the next step.  Its previous gather must be over before it is written again: the wait is
+        queued on the caller's current stream (RCCL) or blocks the host (gloo)."""
+        buf = self._steps % self.nbuf
+        if any(b == buf for b, _ in self._owed):                   # cannot happen with nbuf >= delay
+            raise RuntimeError("GatherRing: buffer re-acquired before its gather was issued")
+        w = self._works[buf]
+        if w is not None:
+            w.wait()
+            self._works[buf] = None
+        self.step_of[buf] = self._steps
+        self._steps += 1
+        return buf
+
+    def commit(self, buf: int, stream=None):
+        """The work that fills ``recs[buf]`` has been queued on ``stream`` (None: the current stream, or host code that
+        has finished)."""
+        if not self.collective:
+            return
+        self._owed.append((buf, stream))
+        while len(self._owed) >= self.delay:
+            self._issue()
+
+    def _issue(self):
+        buf, st = self._owed.pop(0)
+        with (torch.cuda.stream(st) if st is not None else nullcontext()):
+            self._works[buf] = dist.all_gather_into_tensor(self.gathered[buf], self.send[buf], group=self.group,
+                                                           async_op=True)
+
+    def flush(self):
+        """Issue what is owed and wait for every gather in flight."""
+        while self._owed:
+            self._issue()
+        for i, w in enumerate(self._works):
+            if w is not None:
+                w.wait()
+                self._works[i] = None
+
+    def result(self, buf: int) -> torch.Tensor:
+        """Records of all ranks for the step in ``buf``, global order, padding dropped: [sum(counts), width].  Valid
+        once that step's gather has been waited for (``flush``, or the ``acquire`` that hands the buffer out again --
+        before the new step's work is queued)."""
+        if not self.collective:
+            return self.recs[buf]
+        g = self.gathered[buf]
+        if len(set(self.counts)) == 1:
+            return g
+        return torch.cat([g[r * self.rows_max: r * self.rows_max + c] for r, c in enumerate(self.counts)], dim=0)
+
+    def own_rows(self, buf: int) -> torch.Tensor:
+        """This rank's rows inside the gathered buffer (they must equal ``recs[buf]``)."""
+        off = self.rank * self.rows_max
+        return self.gathered[buf][off: off + self.rows] if self.collective else self.recs[buf]

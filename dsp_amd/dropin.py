@@ -175,20 +175,22 @@ def gpu_correlate(a, b=None):
     return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(a))
 
 
-def gpu_spectrum(signal):
-    """airSonar_optimized.py:332-343: |rfft(signal)|, signal [N] or [..., N] (N = the engine's frame length)."""
+def _spectrum(signal, db, what):
     e = get_engine()
-    rows, lead = _rows(signal, e, torch.float64, "gpu_spectrum")
-    out = e.spectrum_rows(rows, db=False)
+    rows, lead = _rows(signal, e, torch.float64, what)
+    # the engine's own frame length runs on its tables; any other length on a plan of its own (echo_spectrum_any)
+    out = e.spectrum_rows(rows, db=db) if rows.shape[1] == e.cfg.n_rx else e.spectrum_any(rows, db=db)
     return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(signal))
 
 
+def gpu_spectrum(signal):
+    """airSonar_optimized.py:332-343: |rfft(signal)|, signal [n] or [..., n], any n (float32 result)."""
+    return _spectrum(signal, False, "gpu_spectrum")
+
+
 def spectrum_db(band_sig):
-    """mag2db(np.fft.rfft(band_sig)), airSonar_optimized.py:710."""
-    e = get_engine()
-    rows, lead = _rows(band_sig, e, torch.float64, "spectrum_db")
-    out = e.spectrum_rows(rows, db=True)
-    return _ret(out.reshape(lead + (out.shape[-1],)), _is_np(band_sig))
+    """mag2db(np.fft.rfft(band_sig)), airSonar_optimized.py:710; any length."""
+    return _spectrum(band_sig, True, "spectrum_db")
 
 
 def mag2db(x):
@@ -214,44 +216,36 @@ def gpu_argmax(signal):
 
 # --------------------------------------------------------------------------- detectors
 def first_strong_peak(corr, fs=None, min_delay_samples=None):
-    """airSonar_optimized.py:200-219.  corr [L] (one band, the reference's call), or [nb,L], or [B,nb,L], with
-    L = the engine's correlation length.  The scalar call returns (peak_idx | None, snr_db); batched calls return
-    (int32 array with -1 for None, snr array).  The blind zone of ``corr`` is zeroed in place, as in the reference."""
+    """airSonar_optimized.py:200-219 with the reference's own arguments: ``corr`` [L] (one band, the reference's call) or
+    [..., L], any L; ``fs`` (default: the engine's) sets the noise window int(SNR_NOISE_MS * fs) and, when
+    ``min_delay_samples`` is None, the blind zone int(fs * CHIRP_LEN * 1.2).  The scalar call returns
+    (peak_idx | None, snr_db); batched calls return (int32 array with -1 for None, snr array) with the leading axes.
+    The blind zone of ``corr`` is zeroed in place, as in the reference (not when pos.size <= min_delay_samples)."""
     e = get_engine()
     cfg = e.cfg
-    if min_delay_samples is not None and int(min_delay_samples) != cfg.min_delay:
-        raise EchoError("min_delay_samples differs from the engine's configuration")
-    if fs is not None and fs != cfg.FS:
-        raise EchoError("fs differs from the engine's configuration")
+    fs = cfg.FS if fs is None else fs
+    md = int(fs * cfg.CHIRP_LEN * 1.2) if min_delay_samples is None else int(min_delay_samples)
+    if md < 0:
+        raise EchoError("min_delay_samples must not be negative")     # (a negative slice bound means something else in NumPy)
+    noise_n = int(cfg.SNR_NOISE_MS * fs)
     is_np = _is_np(corr)
     if is_np and not isinstance(corr, np.ndarray):
         raise EchoError("first_strong_peak writes into corr: pass a NumPy array or a torch tensor")
-    nd = corr.ndim
+    if corr.ndim < 1 or corr.shape[-1] < 1:
+        raise EchoError(f"corr must be [L] or [..., L], got {list(corr.shape)}")
     shape = tuple(corr.shape)
-    if nd not in (1, 2, 3) or shape[-1] != cfg.n_corr or (nd >= 2 and shape[-2] != cfg.n_bands):
-        raise EchoError(f"corr must be [{cfg.n_corr}], [{cfg.n_bands}, {cfg.n_corr}] or [B, {cfg.n_bands}, {cfg.n_corr}], "
-                        f"got {list(shape)}")
-    if nd == 1:
-        full = torch.zeros((1, cfg.n_bands, cfg.n_corr), dtype=torch.float64, device=e.device)
-        full[0, 0] = e._dev(corr, torch.float64)
-        dev = full
-    else:
-        dev = e._dev(corr, torch.float64).reshape((-1, cfg.n_bands, cfg.n_corr))
-        if not is_np and dev.data_ptr() == corr.data_ptr():
-            pass                                        # mutated in place on the device
-    peak, snr, _ = e.first_strong_peak(dev)
-    mutated = dev[0, 0] if nd == 1 else dev.reshape(shape)
+    dev = e._dev(corr, torch.float64)                    # a contiguous float64 tensor on the device is taken as it is
+    in_place = (not is_np) and dev.data_ptr() == corr.data_ptr()
+    peak, snr = e.first_strong_peak_rows(dev.reshape(-1, shape[-1]), md, noise_n, cfg.SNR_GATE_DB)
     if is_np:
-        corr[...] = mutated.cpu().numpy()
+        corr[...] = dev.cpu().numpy()
         peak = peak.cpu().numpy(); snr = snr.cpu().numpy()
-    elif mutated.data_ptr() != corr.data_ptr():
-        corr.copy_(mutated)
-    if nd == 1:
-        p = int(peak[0, 0]); s = float(snr[0, 0])
-        return (None, 0.0) if p < 0 else (p, s)
-    if nd == 2:
-        return peak[0], snr[0]
-    return peak, snr
+    elif not in_place:
+        corr.copy_(dev)
+    if len(shape) == 1:
+        p = int(peak[0]); sn = float(snr[0])
+        return (None, 0.0) if p < 0 else (p, sn)
+    return peak.reshape(shape[:-1]), snr.reshape(shape[:-1])
 
 
 def gpu_envelope_detection(signal, method="hilbert", smooth_window=5):

@@ -188,6 +188,33 @@ class EchoEngine:
         self._call("echo_first_strong_peak", self._h, _ptr(corr), _ptr(peak), _ptr(snr), _ptr(amp), B, self._stream())
         return peak, snr, amp
 
+    def first_strong_peak_rows(self, corr, min_delay: int, noise_n: int, snr_gate_db: float = 6.0):
+        """first_strong_peak(corr, fs, min_delay_samples) with the caller's own arguments (airSonar_optimized.py:200-219)
+        on rows of any length: corr [rows, len] f64, mutated in place (blind zone zeroed), ``noise_n`` = int(SNR_NOISE_MS
+        * fs).  -> (peak_idx i32 [rows] with -1 for None, snr_db f64 [rows])."""
+        if not isinstance(corr, torch.Tensor) or corr.dtype != torch.float64 or not corr.is_contiguous() \
+                or corr.device != self.device or corr.dim() != 2 or corr.shape[1] < 1:
+            raise _lib.EchoError("first_strong_peak_rows mutates corr in place: it must be a contiguous float64 tensor "
+                                 f"[rows, len] on {self.device}")
+        if min_delay < 0 or noise_n < 0:
+            raise _lib.EchoError("first_strong_peak_rows: min_delay and noise_n must not be negative")
+        rows, L = corr.shape
+        peak = self._empty((rows,), torch.int32)
+        snr = self._empty((rows,), torch.float64)
+        self._call("echo_first_strong_peak_rows", _ptr(corr), rows, L, int(min_delay), int(noise_n), float(snr_gate_db),
+                   _ptr(peak), _ptr(snr), self._stream())
+        return peak, snr
+
+    def spectrum_any(self, x, db=False):
+        """gpu_spectrum / mag2db(np.fft.rfft(x)) for rows of any length (airSonar_optimized.py:332-343, :710).
+        x [rows, n] f64 -> [rows, n // 2 + 1] f32."""
+        x = self._dev(x, torch.float64)
+        if x.dim() != 2 or x.shape[1] < 1:
+            raise _lib.EchoError(f"spectrum_any takes [rows, n >= 1], got {list(x.shape)}")
+        out = self._empty((x.shape[0], x.shape[1] // 2 + 1), torch.float32)
+        self._call("echo_spectrum_any", _ptr(x), _ptr(out), 1 if db else 0, x.shape[0], x.shape[1], self._stream())
+        return out
+
     def argmax(self, x):
         x = self._dev(x, torch.float64)
         if x.dim() < 1 or x.shape[-1] < 1:

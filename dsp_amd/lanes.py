@@ -94,7 +94,7 @@ class ChainLanes:
                     C.c_void_p(kdone.cuda_event)), "echo_chain_ordered")
                 self._kal_done = kdone
             if want_event:
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=True)
                 done.record(stream)
         return done
 

@@ -114,6 +114,8 @@ typedef struct EchoHandle EchoHandle;
  * runs with spec_db = NULL only).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
+ * echo_chain_full takes every even correlation length of the single-workgroup kernels: where half of it has a large prime
+ * factor (e.g. 4562 = 2 * 2281) the Hilbert transform runs as Bluestein convolutions, as in echo_envelope_rows.
  * iir_ncoef = 1 with n_taps = 1 is the identity filter ([1], [1], [1]) design_filters falls back to (:178-182); zi may
  * then be NULL.  ECHO_ERR_UNSUPPORTED from echo_create: IIR order other than 0, 6 or 8 (iir_ncoef 1 / 13 / 17), or a frame so long that one
  * frame's detector input exceeds a workgroup's 160 KB of LDS (about 20,000 lags). */
@@ -142,6 +144,14 @@ int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, in
  * band, so any number of rows is taken. */
 int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int rows, void* stream);
 
+/* gpu_spectrum / mag2db(np.fft.rfft(x)) for signals of ANY length n (airSonar_optimized.py:332-343, :710; np.fft.rfft
+ * has no length restriction): x[rows][n] float64 -> spec[rows][n/2+1] float32, |X| or its dB as echo_spectrum.  No
+ * handle: a length the FFT kernels hold (even n up to about 19,000 whose half has small prime factors or fits the
+ * Bluestein kernels, odd n up to about 6600) gets a plan of its own on first use, kept per (device, n) until the process
+ * ends; every other length up to 2^18 runs as direct float64 sums (O(n^2) per row, exact to rounding).  Thread-safe.
+ * ECHO_ERR_UNSUPPORTED: n beyond 2^18 without an FFT plan. */
+int echo_spectrum_any(const double* x, float* spec, int db, int rows, int n, void* stream);
+
 /* gpu_mag2db / mag2db on an arbitrary array (airSonar_optimized.py:345-357). */
 int echo_mag2db(const float* x, float* out, size_t n, void* stream);
 
@@ -159,6 +169,16 @@ int echo_xcorr(const double* a, const double* b, double* out, int rows, int n, i
  * mutated array (airSonar_optimized.py:666) when `amplitude` is non-NULL. */
 int echo_first_strong_peak(EchoHandle* h, double* corr, int32_t* peak_idx, double* snr_db,
                            double* amplitude, int B, void* stream);
+
+/* first_strong_peak(corr, fs, min_delay_samples) with the caller's own arguments (airSonar_optimized.py:200-219): rows
+ * of any length `len` (pos = corr[len/2:]), any blind zone min_delay (= min_delay_samples, or int(fs * CHIRP_LEN * 1.2)
+ * when the caller passes None), noise window noise_n = int(SNR_NOISE_MS * fs) samples behind it (truncated at the end of
+ * pos like the reference's slice), gate snr_gate_db (6.0 in the reference).  corr[rows][len] float64 is mutated as the
+ * reference mutates it (pos[:min_delay] = 0) unless pos.size <= min_delay, which gives (-1, 0.0) and leaves the row
+ * alone (:206-207).  peak_idx[rows] = np.argmax(pos) (first index on ties; -1 = None), snr_db[rows].  No handle.
+ * ECHO_ERR_UNSUPPORTED: a noise window of more than 8192 samples. */
+int echo_first_strong_peak_rows(double* corr, int rows, int len, int min_delay, int noise_n, double snr_gate_db,
+                                int32_t* peak_idx, double* snr_db, void* stream);
 
 /* gpu_envelope_detection(corr, 'hilbert', smooth_window=5) and the envelope-path peak choice of _process_band_gpu
  * (airSonar_optimized.py:431-475, :642-654; calculate_signal_quality :477-490; scipy.signal.hilbert,

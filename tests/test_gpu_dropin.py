@@ -295,13 +295,87 @@ def test_mis_shaped_arguments_raise_instead_of_reaching_a_kernel(engines):
     from dsp_amd import dropin as D
     D.use_engine(e)
     with pytest.raises(EchoError):
-        D.first_strong_peak(np.zeros(L - 1), cfg.FS)
+        D.first_strong_peak(np.zeros(L), cfg.FS, -1)
     with pytest.raises(EchoError):
-        D.first_strong_peak(np.zeros(L), cfg.FS, cfg.min_delay + 1)
+        D.first_strong_peak([0.0] * L, cfg.FS)                     # the blind zone is written into corr: no lists
     with pytest.raises(EchoError):
-        D.gpu_spectrum(np.zeros(N - 2))
+        D.gpu_spectrum(np.zeros((2, 0)))
     with pytest.raises(EchoError):
         D.bandpass(np.zeros(N + 1, f32), D.design_filters()[0])
     # and the engine still works afterwards
     rec, spec = e.chain(rx)
     assert rec.shape == (4, 64) and spec.shape == (4, nb, bins)
+
+
+def test_first_strong_peak_with_the_callers_own_arguments(engines, gold_distinct):
+    """first_strong_peak(corr, fs, min_delay_samples) (airSonar_optimized.py:200-219) for any correlation length, blind
+    zone and sample rate -- the noise window is int(SNR_NOISE_MS * fs) samples, the default blind zone
+    int(fs * CHIRP_LEN * 1.2): index, SNR and the in-place zeroing against the oracle's restatement; even and odd
+    counts in the noise window, a window cut short by the end of pos, ties, silence, pos no longer than the blind zone."""
+    from dsp_amd import dropin as D
+    e = engines["distinct"]
+    D.use_engine(e)
+    cfg = e.cfg
+    rng = np.random.default_rng(12)
+    g = gold_distinct
+    cases = [(4556, 48000, None), (4556, 48000, 331), (4556, 48000, 0), (4556, 48000, 1000), (4556, 44100, 500),
+             (4555, 48000, 331), (13229, 44100, 500), (901, 48000, 100), (700, 48000, 300), (700, 9800, 349),
+             (640, 48000, 320), (640, 48000, 5000), (2, 48000, 0), (1, 48000, 0), (30001, 96000, 2000)]
+    for L, fs, md in cases:
+        t = np.arange(L)
+        corr = rng.standard_normal(L) * 0.1 + 3.0 * np.exp(-((t - int(L * 0.8)) / 6.0) ** 2) * np.cos(0.7 * t)
+        want_c = corr.copy()
+        want = O.first_strong_peak(want_c, fs, cfg, md)
+        got_c = corr.copy()
+        got = D.first_strong_peak(got_c, fs, md)
+        assert (got[0] is None) == (want[0] is None), (L, fs, md, got, want)
+        if want[0] is not None:
+            assert got[0] == int(want[0]) and got[1] == pytest.approx(float(want[1]), rel=1e-12), (L, fs, md)
+        else:
+            assert got == (None, 0.0)
+        assert np.array_equal(got_c, want_c), (L, fs, md)
+    # the reference's own correlations, batched [frames, bands, L], another blind zone
+    corr = g["stage_corr"][:4].copy()
+    peak, snr = D.first_strong_peak(corr, cfg.FS, 700)
+    assert peak.shape == (4, 3) and peak.dtype == np.int32
+    for k in range(4):
+        for j in range(3):
+            c = g["stage_corr"][k, j].copy()
+            p, sn = O.first_strong_peak(c, cfg.FS, cfg, 700)
+            assert peak[k, j] == (-1 if p is None else p) and snr[k, j] == pytest.approx(sn, rel=1e-12)
+            assert np.array_equal(corr[k, j], c)
+    # ties take the first index; silence and a constant are gated
+    tie = np.zeros(1200); tie[600:] = 0.001 * np.sin(np.arange(600)); tie[[900, 1000]] = 5.0
+    want = O.first_strong_peak(tie.copy(), 48000, cfg, 100)
+    assert D.first_strong_peak(tie.copy(), 48000, 100)[0] == want[0] == 300
+    assert D.first_strong_peak(np.zeros(4556), 48000) == (None, 0.0)
+    assert D.first_strong_peak(np.full(4556, 0.25), 48000) == O.first_strong_peak(np.full(4556, 0.25), 48000, cfg)
+    # a device tensor is mutated where it lies
+    c = torch.from_numpy(g["stage_corr"][0, 0].copy()).to(e.device)
+    p, _ = D.first_strong_peak(c, cfg.FS)
+    assert p == g["peak_idx"][int(g["stage_frames"][0]), 0] and bool((c[cfg.half:cfg.half + cfg.min_delay] == 0).all())
+
+
+def test_spectrum_of_any_length(engines):
+    """gpu_spectrum / mag2db(np.fft.rfft(x)) (airSonar_optimized.py:332-343, :710) for lengths other than the engine's
+    frame: lengths the FFT kernels hold (a plan per length), lengths only the direct sums take (a large prime, an odd
+    length beyond a workgroup's LDS, tiny ones), rows; |dX| / max|X| <= 1e-4 against NumPy."""
+    from dsp_amd import dropin as D
+    D.use_engine(engines["default"])
+    rng = np.random.default_rng(3)
+    for n in (4282, 4800, 8820, 4795, 1000, 64, 4283, 9973, 19997, 8821, 63, 7, 2, 1, 6000, 12000):
+        t = np.arange(n)
+        x = rng.standard_normal(n) * 0.1 + np.sin(2 * np.pi * 0.11 * t) + 0.3 * np.cos(2 * np.pi * 0.31 * t)
+        ref = np.abs(np.fft.rfft(x))
+        mag = D.gpu_spectrum(x)
+        assert mag.shape == ref.shape and mag.dtype == np.float32, n
+        assert np.abs(mag - ref).max() <= 1e-4 * max(ref.max(), 1e-30), (n, np.abs(mag - ref).max() / ref.max())
+        db = D.spectrum_db(x)
+        lin = 10 ** (db.astype(np.float64) / 20)
+        assert np.abs(lin - np.maximum(ref, 1e-12)).max() <= 1e-4 * max(ref.max(), 1e-30), n
+    x = rng.standard_normal((2, 3, 1500))
+    mag = D.gpu_spectrum(x)
+    assert mag.shape == (2, 3, 751)
+    assert np.abs(mag[1, 2] - np.abs(np.fft.rfft(x[1, 2]))).max() <= 1e-4 * np.abs(np.fft.rfft(x[1, 2])).max()
+    tt = torch.from_numpy(x[0]).cuda()
+    assert torch.is_tensor(D.gpu_spectrum(tt)) and D.gpu_spectrum(tt).shape == (3, 751)
