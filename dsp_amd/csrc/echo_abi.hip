@@ -16,6 +16,7 @@ using namespace echo;
 
 constexpr int kEvPerSlot = 6;               // timing events per profiled chain call
 constexpr int kInnerChunk = 8192;          // frames per pass when a many-pass call pipelines its own IIRs
+constexpr int kSpecDftMax = 1 << 18;       // spectra by direct sums: n^2 / 2 complex multiply-adds per row
 
 // Device scratch of one internal pass of the chain: everything beyond the caller's inputs and outputs.
 struct Scratch {
@@ -59,6 +60,7 @@ struct EchoHandle {
     hipStream_t last_stream = nullptr;
     bool last_stream_set = false;
     hipEvent_t xs_event = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;   // ECHO_IIR_SIDE experiment
     int device = 0;
     bool bodd0 = false;
     BandParams base;                       // sizes, layout and device table pointers
@@ -71,6 +73,7 @@ struct EchoHandle {
     float2* d_uk = nullptr;
     cpx<float> *d_lroots = nullptr, *d_lwn = nullptr, *d_luk = nullptr;   // long path: spectrum FFT tables
     cpx<float> *d_lbw = nullptr, *d_lbhat = nullptr;                       // long path, odd N: chirp factors and filter spectrum
+    double2* d_dftw = nullptr;             // long path, frame lengths no FFT kernel holds: the N roots of unity of the direct sums
     cpx<double> *d_cfg = nullptr, *d_cfw2 = nullptr, *d_cftw = nullptr;   // long path: FFT matched filter tables
     // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
     hipStream_t pf_stream = nullptr;
@@ -108,6 +111,9 @@ struct EchoHandle {
     int inner_pipeline = 1;                // ECHO_INNER_PIPELINE=0: calls of many passes run their IIRs in line
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
     int iir_lps = 0;                       // lanes per sequence in the quad kernel: 0 = choose, 4 or 16 (ECHO_IIR_LPS)
+    int iir_prio = 0;                      // wave priority of the quad IIR kernel (ECHO_IIR_PRIO, experiments)
+    int iir_side = 0;                      // ECHO_IIR_SIDE=1: the chain's IIR runs on one stream shared by every handle
+                                           // of the device (ECHO_IIR_CUS=n: created with a mask of n compute units)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
@@ -128,6 +134,25 @@ struct EchoHandle {
 };
 
 namespace {
+
+// Experiment: one stream per device on which the IIRs of every handle run one after the other, optionally confined
+// to a subset of the compute units.
+std::mutex g_side_mu;
+hipStream_t g_side_stream[kMaxDevices];
+hipStream_t side_stream(int device) {
+    std::lock_guard<std::mutex> guard(g_side_mu);
+    if (g_side_stream[device]) return g_side_stream[device];
+    hipStream_t st = nullptr;
+    int ncu = 0;
+    if (const char* m = std::getenv("ECHO_IIR_CUS")) ncu = std::atoi(m);
+    if (ncu > 0) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ncu && i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    g_side_stream[device] = st;
+    return st;
+}
 
 template <class T> int dev_upload(T** dst, const T* src, size_t n) {
     if (hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T)) != hipSuccess) return ECHO_ERR_NOMEM;
@@ -231,6 +256,7 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, dou
     p.rx = rx; p.y = y; p.fwd = fwd ? fwd : h->sc.fwd; p.b = h->d_b; p.a = h->d_a; p.zi = h->d_zi;
     p.B = B; p.N = h->cfg.n_rx; p.P = 3 * h->cfg.iir_ncoef; p.nb = h->cfg.n_bands;
     p.y_aligned16 = (p.N % 2 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+    p.prio = h->iir_prio;
     const long lane_waves = (long)p.nb * ((B + 63) / 64);
     const bool quad = h->iir_mode == 2 || (h->iir_mode == 0 && lane_waves <= (corun ? 383 : 480));   // up to ~10k frames
     if (quad) {
@@ -343,6 +369,15 @@ bool detector_supported(const EchoHandle* h) {
     return h->long_path ? (d >= ECHO_DET_MEDIAN && d <= ECHO_DET_TWOPEAK) : (d == ECHO_DET_MEDIAN || d == ECHO_DET_MEANPOW);
 }
 
+// spectra of long frames: the mixed-radix / chirp-z kernel where the frame length has a plan, direct sums otherwise
+bool long_spec_available(const EchoHandle* h) { return h->lbase.has_spec || h->d_dftw; }
+int run_long_spec(const EchoHandle* h, const LongParams& q, int rows_frames, hipStream_t s) {
+    if (h->lbase.has_spec) return launch_long_spec(q, rows_frames, s);
+    if (!h->d_dftw) return ECHO_ERR_UNSUPPORTED;
+    const int rc = launch_dft_rows(q.spec_in, h->d_dftw, q.spec_out, q.spec_db, rows_frames * q.nb, q.N, s);
+    return rc == 0 ? ECHO_OK : ECHO_ERR_HIP;
+}
+
 }  // namespace
 
 extern "C" {
@@ -381,6 +416,8 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (const char* m = std::getenv("ECHO_INNER_PIPELINE")) h->inner_pipeline = std::atoi(m);
     if (const char* m = std::getenv("ECHO_LANES")) h->self_lanes = std::atoi(m);
     if (const char* m = std::getenv("ECHO_FUSE_DET")) h->fuse_det = std::atoi(m);
+    if (const char* m = std::getenv("ECHO_IIR_PRIO")) h->iir_prio = std::atoi(m);
+    if (const char* m = std::getenv("ECHO_IIR_SIDE")) h->iir_side = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
     // device address of this GPU's copy of the static scratch array, looked up once per device
@@ -472,6 +509,17 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
                 h->lbase.sbw = h->d_lbw; h->lbase.sbhat = h->d_lbhat;
             }
         }
+        if (!h->lbase.has_spec && cfg->n_rx <= kSpecDftMax) {
+            // a frame length none of the FFT kernels takes (e.g. an odd N beyond one workgroup's LDS): spectra as direct
+            // float64 sums, O(N^2) per frame and band
+            std::vector<double2> w((size_t)cfg->n_rx);
+            const long double tau = 6.283185307179586476925286766559005768L;
+            for (int t = 0; t < cfg->n_rx; ++t) {
+                const long double a = -tau * (long double)t / (long double)cfg->n_rx;
+                w[t] = double2{(double)cosl(a), (double)sinl(a)};
+            }
+            up(dev_upload(&h->d_dftw, w.data(), w.size()));
+        }
         if (const char* st = std::getenv("ECHO_DET_STAGES")) h->lbase.det_stages = std::atoi(st);   // development aids
         if (const char* st = std::getenv("ECHO_DET_PASSES")) h->lbase.det_passes = std::atoi(st);
         if (const char* cf = std::getenv("ECHO_CORR_FFT")) h->lbase.cf_use = h->lbase.cf_use && std::atoi(cf) != 0;   // development override
@@ -524,16 +572,25 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
 
 void echo_destroy(EchoHandle* h) {
     if (!h) return;
-    for (EchoHandle*& c : h->lane_clone) { if (c) { free_scratch(c); delete c; c = nullptr; } }
+    for (EchoHandle*& c : h->lane_clone) {
+        if (!c) continue;
+        free_scratch(c);
+        if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+        if (c->side_join) (void)hipEventDestroy(c->side_join);
+        if (c->xs_event) (void)hipEventDestroy(c->xs_event);
+        delete c; c = nullptr;
+    }
     for (hipStream_t& st : h->lane_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
     if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
     for (hipEvent_t e : h->lane_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->lane_kal) if (e) (void)hipEventDestroy(e);
     if (h->xs_event) (void)hipEventDestroy(h->xs_event);
+    if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+    if (h->side_join) (void)hipEventDestroy(h->side_join);
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
-                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw};
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
@@ -686,7 +743,7 @@ int echo_spectrum(EchoHandle* h, const double* band_sig, float* spec, int db, in
             LongParams q = h->lbase;
             q.spec_db = db ? 1 : 0;
             q.spec_in = band_sig + (size_t)f0 * q.nb * q.N; q.spec_out = spec + (size_t)f0 * q.nb * q.nbins;
-            if (int rc = launch_long_spec(q, std::min(h->max_chunk, B - f0), static_cast<hipStream_t>(stream))) return rc;
+            if (int rc = run_long_spec(h, q, std::min(h->max_chunk, B - f0), static_cast<hipStream_t>(stream))) return rc;
         }
         return ECHO_OK;
     }
@@ -862,7 +919,7 @@ int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int 
             LongParams q = h->lbase;
             q.nb = 1; q.spec_db = db ? 1 : 0;
             q.spec_in = x + (size_t)r0 * q.N; q.spec_out = spec + (size_t)r0 * q.nbins;
-            rc = launch_long_spec(q, nr, s);
+            rc = run_long_spec(h, q, nr, s);
         } else {
             BandParams p = h->base;
             p.nb = 1; p.spec_db = db ? 1 : 0;
@@ -890,7 +947,6 @@ int echo_first_strong_peak_rows(double* corr, int rows, int len, int min_delay, 
 namespace {
 struct SpecPlan { int device = -1, n = 0; EchoHandle* h = nullptr; double2* roots = nullptr; };
 constexpr int kSpecPlans = 16;
-constexpr int kSpecDftMax = 1 << 18;                        // direct sums: n^2 / 2 complex multiply-adds per row
 std::mutex g_spec_mu;
 std::vector<SpecPlan> g_spec_plans;
 
@@ -910,7 +966,7 @@ int spec_plan_for(int n, SpecPlan** out) {
         c.b = &one; c.a = &one; c.zi = nullptr; c.taps = &one; c.chirps = &one;
         EchoHandle* h = nullptr;
         if (echo_create(&c, &h) == ECHO_OK) {
-            if (h->long_path && !h->lbase.has_spec) { echo_destroy(h); h = nullptr; }
+            if (h->long_path && !h->lbase.has_spec) { echo_destroy(h); h = nullptr; }   // direct sums need no handle
             pl.h = h;
         }
     }
@@ -1035,7 +1091,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
     const bool kal = kalman_x || kalman_p || kalman_init;
     if (kal && (!kalman_x || !kalman_p || !kalman_init || n_streams < 1 || B % n_streams != 0)) return ECHO_ERR_INVALID;
     if (!detector_supported(h)) return ECHO_ERR_UNSUPPORTED;
-    if (h->long_path && spec_db && !h->lbase.has_spec) return ECHO_ERR_UNSUPPORTED;
+    if (h->long_path && spec_db && !long_spec_available(h)) return ECHO_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = h->cfg.n_bands, N = h->cfg.n_rx;
     // frames are processed in passes of at most max_chunk; with a Kalman state each pass must hold whole
@@ -1083,6 +1139,16 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 if (rc) return rc;
                 h->pf_valid = false;
             }
+        } else if (h->iir_side && !ext && !h->capturing) {
+            hipStream_t side = side_stream(h->device);
+            if (!side) return ECHO_ERR_HIP;
+            if (!h->side_fork && (hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming) != hipSuccess ||
+                                  hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming) != hipSuccess)) return ECHO_ERR_HIP;
+            std::lock_guard<std::mutex> guard(g_side_mu);
+            if (hipEventRecord(h->side_fork, s) != hipSuccess || hipStreamWaitEvent(side, h->side_fork, 0) != hipSuccess) return ECHO_ERR_HIP;
+            rc = run_iir(h, rx + (size_t)f0 * N, sc.y, n, side, sc.fwd);
+            if (rc) return rc;
+            if (hipEventRecord(h->side_join, side) != hipSuccess || hipStreamWaitEvent(s, h->side_join, 0) != hipSuccess) return ECHO_ERR_HIP;
         } else {
             rc = run_iir(h, rx + (size_t)f0 * N, sc.y, n, s, sc.fwd);
             if (rc) return rc;
@@ -1108,7 +1174,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             if (rc) return rc;
             if (spec_db) {
                 q.spec_db = 1; q.spec_in = sc.band; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;
-                rc = launch_long_spec(q, n, s);
+                rc = run_long_spec(h, q, n, s);
                 if (rc) return rc;
             }
         } else if (full) {
@@ -1219,6 +1285,7 @@ static EchoHandle* clone_for_lane(const EchoHandle* h) {
     for (int i = 0; i < 3; ++i) { c->lane_stream[i] = nullptr; c->lane_join[i] = nullptr; c->lane_kal[i] = nullptr; }
     c->lane_fork = nullptr; c->lanes_ready = false;
     c->last_stream = nullptr; c->last_stream_set = false; c->xs_event = nullptr;
+    c->side_fork = nullptr; c->side_join = nullptr;
     return c;
 }
 
@@ -1255,7 +1322,7 @@ static int chain_entry(EchoHandle* h, const float* rx, EchoResult* out, float* s
                        (!kal || (kalman_x && kalman_p && kalman_init && n_streams >= 1 && n_streams <= chunk &&
                                  B % n_streams == 0)) &&
                        !(full && (h->long_path || !h->has_env || !hilb_fits(h->base.N, h->base.n2))) &&
-                       detector_supported(h) && !(h->long_path && spec_db && !h->lbase.has_spec);
+                       detector_supported(h) && !(h->long_path && spec_db && !long_spec_available(h));
     if (!lanes)
         return chain_impl(h, rx, out, spec_db, kalman_x, kalman_p, kalman_init, B, n_streams, stream, full, quality,
                           nullptr, corr_out, kal_wait, kal_done);

@@ -19,6 +19,7 @@ struct IirParams {
     const double* zi;     // [nb][NC-1]
     int B, N, P, nb, ntiles;
     int y_aligned16;      // y base and every row start are 16-byte aligned (N even): 16-byte stores allowed
+    int prio;             // 0..3: wave priority the kernel asks for (s_setprio); the recurrence is a latency chain
 };
 
 struct FuseParams {

@@ -359,6 +359,9 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     constexpr int QF = 64 / LPS;                // frames per wave
     __shared__ __attribute__((aligned(16))) float xt_all[QW][2][QF * XS];
     __shared__ __attribute__((aligned(16))) double yt_all[QW][QF * YS];
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int wave = threadIdx.x >> 6;
     float (*xt)[QF * XS] = xt_all[wave];
     double* yt = yt_all[wave];

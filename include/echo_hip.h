@@ -109,9 +109,10 @@ typedef struct EchoHandle EchoHandle;
 
 /* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
  * (airSonar_optimized.py:598-619).  Uses the current HIP device.
- * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution that must fit a
- * workgroup's LDS (odd n_rx up to about 6600; beyond that the spectrum calls return ECHO_ERR_UNSUPPORTED and the chain
- * runs with spec_db = NULL only).  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
+ * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution where that fits a
+ * workgroup's LDS (odd n_rx up to about 6600); frame lengths no FFT kernel holds (longer odd ones, even ones whose half
+ * has a prime factor the mixed-radix passes do not take) get their spectra as direct float64 sums, O(n_rx^2) per frame
+ * and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
  * echo_chain_full takes every even correlation length of the single-workgroup kernels: where half of it has a large prime

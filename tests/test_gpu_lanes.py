@@ -93,3 +93,37 @@ def test_lanes_with_batches_of_several_internal_passes():
         assert torch.equal(outs[i], want[i]), f"batch {i}: records differ"
     assert torch.equal(kal2.x, kal.x)
     ln.close(); eng.close()
+
+
+@pytest.mark.parametrize("env", [{"ECHO_IIR_SIDE": "1"}, {"ECHO_IIR_SIDE": "1", "ECHO_IIR_CUS": "192"},
+                                 {"ECHO_IIR_PRIO": "3"}])
+def test_scheduling_switches_leave_the_bytes_alone(env, monkeypatch):
+    """The switches behind the scheduling measurements -- every handle's IIR on one stream shared by the device
+    (ECHO_IIR_SIDE), that stream confined to a subset of the compute units (ECHO_IIR_CUS), the IIR's waves at a raised
+    priority (ECHO_IIR_PRIO) -- change where and when the kernels run, not what they compute: three batches in flight
+    give the bytes of the plain engine."""
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.lanes import ChainLanes
+    cfg = C.optimized_config(C.BANDS_DISTINCT)
+    plain = EchoEngine(cfg)
+    S, sizes = 16, [16 * 40, 16 * 7, 16 * 64, 16 * 3, 16 * 33]
+    rx = torch.from_numpy(synth_frames(sum(sizes), cfg, plain.tables.tx_pcm, start=777)).cuda()
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    kal = BatchedKalman(plain, S)
+    want = [tuple(t.clone() for t in plain.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal)) for i in range(len(sizes))]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = EchoEngine(cfg)
+    ln = ChainLanes(eng, 3)
+    for k in env:
+        monkeypatch.delenv(k)
+    kal2 = BatchedKalman(eng, S)
+    outs = [torch.empty((n, 64), dtype=torch.uint8, device="cuda") for n in sizes]
+    specs = [torch.empty((n, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device="cuda") for n in sizes]
+    for i in range(len(sizes)):
+        ln.submit(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal2, out=outs[i], spec_out=specs[i])
+    ln.join(); torch.cuda.synchronize()
+    for i in range(len(sizes)):
+        assert torch.equal(outs[i], want[i][0]) and torch.equal(specs[i], want[i][1]), i
+    assert torch.equal(kal2.x, kal.x)
+    ln.close(); eng.close(); plain.close()

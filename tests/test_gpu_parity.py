@@ -192,12 +192,38 @@ def test_chain_with_other_frame_lengths_vs_oracle(kind, listen, chirp):
     e.close()
 
 
+def test_full_chain_with_a_correlation_length_whose_half_is_prime():
+    """M = 281 with the default frame gives L = 4562 = 2 * 2281 (prime): the Hilbert transform of the correlation's
+    envelope branch then runs its half-length FFTs as Bluestein convolutions.  Full chain (peak indices, validity,
+    confidence with both quality scores) and the standalone envelope detection against the oracle."""
+    from dataclasses import replace
+    cfg = replace(C.optimized_config(C.BANDS_DISTINCT), CHIRP_LEN_FIXED=281.5 / 48000)
+    assert cfg.n_chirp == 281 and cfg.n_corr == 4562
+    e = _engine(cfg)
+    t = e.tables
+    rx = synth_frames(64, cfg, t.tx_pcm, start=17)
+    rec, _ = e.chain(rx, mode="full")
+    check_records(_rec(rec), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="full"))
+    rec_named, _ = e.chain(rx)
+    check_records(_rec(rec_named), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="named"))
+    corr = e.correlate(e.bandpass_bank(rx[:4]))
+    r = e.envelope_detection(corr)
+    for i in range(4):
+        for j in range(cfg.n_bands):
+            env, peaks, q = O.gpu_envelope_detection(corr[i, j].cpu().numpy(), 5)
+            got = r["peaks"][i, j].cpu().numpy()
+            assert np.array_equal(got[got >= 0], peaks)
+            assert abs(float(r["quality"][i, j]) - q) <= 1e-9
+            assert np.abs(r["envelope"][i, j].cpu().numpy() - env).max() <= 1e-11 * env.max()
+    e.close()
+
+
 def test_chain_with_odd_frame_length():
     """An odd number of samples per frame (N = 4795; np.fft.rfft has no length restriction, airSonar_optimized.py:710):
     no half-length packing exists, the spectrum is a chirp-z convolution through the mixed-radix FFT; everything else of
     the chain runs on the tiled kernels.  Against the oracle, spectra included, through the chain and through the
-    standalone entry point.  An odd frame too long for that convolution to fit a workgroup's LDS (N = 8821) still
-    runs without spectra and refuses them."""
+    standalone entry point.  An odd frame too long for that convolution to fit a workgroup's LDS (N = 8821) gets its
+    spectra as direct float64 sums."""
     from dsp_amd._lib import EchoError
     from dataclasses import replace
     cfg = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=0.0999)
@@ -219,10 +245,12 @@ def test_chain_with_odd_frame_length():
     assert cfg.n_rx == 8821
     e = _engine(cfg)
     rx = synth_frames(8, cfg, e.tables.tx_pcm, start=5)
+    exp = O.chain(rx, e.tables.chirps_f32, e.tables.filters, cfg, mode="named", keep=("spec_db",))
     rec, _ = e.chain(rx, want_spectra=False)
-    check_records(_rec(rec), O.chain(rx, e.tables.chirps_f32, e.tables.filters, cfg, mode="named"))
-    with pytest.raises(EchoError):
-        e.chain(rx, want_spectra=True)
+    check_records(_rec(rec), exp)
+    rec2, spec = e.chain(rx, want_spectra=True)                # no FFT kernel holds this length: direct float64 sums
+    assert torch.equal(rec, rec2) and spec.shape == (8, cfg.n_bands, 4411)
+    check_spectra(spec.cpu().numpy(), exp["spec_db"])
     e.close()
 
 
