@@ -82,6 +82,7 @@ struct EchoHandle {
     hipEvent_t pf_rx_ready = nullptr;               // multi-pass calls: the caller's stream at call entry
     hipEvent_t chain_end[2] = {nullptr, nullptr};   // end of the last two chain calls (alternating)
     int chain_gen = 0; bool chain_end_set[2] = {false, false};
+    hipEvent_t band_end = nullptr; bool band_end_set = false;   // behind the band stage of the latest chain call
     int pf_gate = 1;                                // 1: a prefetch starts when the chain call before the latest one has
                                                     // finished, i.e. it runs under the latest call's band kernel; 0: as soon as
                                                     // its buffer is free (ECHO_PF_GATE overrides, for experiments)
@@ -286,6 +287,7 @@ int ensure_prefetch(EchoHandle* h, int frames) {
         if (hipEventCreateWithFlags(&h->pf_rx_ready, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&h->chain_end[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
+        if (hipEventCreateWithFlags(&h->band_end, hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
         if (const char* g = std::getenv("ECHO_PF_GATE")) h->pf_gate = std::atoi(g);
     }
     if (frames <= h->pf_cap) return ECHO_OK;
@@ -314,7 +316,9 @@ int issue_prefetch(EchoHandle* h, const float* rx, int B, hipEvent_t after, bool
         h->pf_consumed_set[slot] = false;
     }
     if (after && hipStreamWaitEvent(h->pf_stream, after, 0) != hipSuccess) return ECHO_ERR_HIP;
-    if (gate && h->pf_gate && h->chain_end_set[h->chain_gen ^ 1])
+    if (gate && h->pf_gate == 2) {
+        if (h->band_end_set) (void)hipStreamWaitEvent(h->pf_stream, h->band_end, 0);
+    } else if (gate && h->pf_gate && h->chain_end_set[h->chain_gen ^ 1])
         (void)hipStreamWaitEvent(h->pf_stream, h->chain_end[h->chain_gen ^ 1], 0);
     (void)hipEventRecord(h->pf_t0, h->pf_stream);
     const int rc = run_iir(h, rx, h->pf_y[slot], B, h->pf_stream, h->pf_fwd, true);
@@ -601,7 +605,7 @@ void echo_destroy(EchoHandle* h) {
         (void)hipStreamSynchronize(h->pf_stream);
         (void)hipStreamDestroy(h->pf_stream);
         hipEvent_t evs[] = {h->pf_ready[0], h->pf_ready[1], h->pf_consumed[0], h->pf_consumed[1], h->pf_t0, h->pf_t1,
-                            h->chain_end[0], h->chain_end[1], h->pf_rx_ready};
+                            h->chain_end[0], h->chain_end[1], h->pf_rx_ready, h->band_end};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     (void)hipFree(h->pf_y[0]); (void)hipFree(h->pf_y[1]); (void)hipFree(h->pf_fwd);
@@ -1200,6 +1204,10 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             }
             if (rc) return rc;
         }
+        if (!ext && h->pf_stream && !h->capturing && h->pf_gate == 2) {
+            (void)hipEventRecord(h->band_end, s);
+            h->band_end_set = true;
+        }
         if (pre) {                                         // the band kernels were the last readers of the prefetched IIR output
             if (hipEventRecord(h->pf_consumed[pre_slot], s) != hipSuccess) return ECHO_ERR_HIP;
             h->pf_consumed_set[pre_slot] = true;
@@ -1279,6 +1287,7 @@ static EchoHandle* clone_for_lane(const EchoHandle* h) {
         c->pf_consumed_set[i] = c->chain_end_set[i] = false; c->pf_y[i] = nullptr; c->lane_clone[i] = nullptr;
     }
     c->pf_fwd = nullptr; c->pf_cap = 0; c->pf_rx = nullptr; c->pf_B = 0; c->pf_valid = false;
+    c->band_end = nullptr; c->band_end_set = false;
     c->env_plans.clear(); c->d_env_rows = nullptr; c->env_rows_cap = 0;
     c->prof = false; c->ev.clear(); c->prof_pair.clear(); c->prof_slots = c->prof_used = 0;
     c->capturing = false; c->live_graphs = 0; c->self_lanes = 0;
