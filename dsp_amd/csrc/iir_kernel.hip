@@ -339,14 +339,6 @@ struct Df2tRow {
 };
 
 constexpr int QW = 4;       // waves per workgroup: one per SIMD of the compute unit that receives the workgroup
-// LDS tiles of the quad kernel, sized so that a workgroup takes 27.6 KB instead of 52 KB: the workgroup lives for the
-// whole kernel on its compute unit, and what it holds there is what the kernels of other streams cannot use.
-//   rx tile: two buffers of 32 columns (row stride XM) while the frame streams through; the same memory as one buffer of
-//   64 columns (row stride XS) during the two odd extensions, which read up to 52 samples from one end of the frame
-//   output tile: 16 samples per flush (row stride YH)
-constexpr int XM = 36;      // floats; 16-byte aligned rows, same bank pattern as XS (both are 4 mod 32)
-constexpr int YH = 18;      // doubles; 16-byte aligned rows
-constexpr int HB = CH / 2;  // samples per output flush and per register buffer of the backward pass
 
 // One-wave workgroups leave the choice of SIMD to the dispatcher, which was seen to stack two or three of these
 // latency-chains on one SIMD after some predecessors (0.79 ms instead of 0.59 ms per 4096 frames); a four-wave
@@ -365,15 +357,13 @@ template <int NC> struct IirFilt<NC, 16> {
 template <int NC, int LPS>
 __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p) {
     constexpr int QF = 64 / LPS;                // frames per wave
-    constexpr int XREG = (2 * QF * XM > QF * XS) ? 2 * QF * XM : QF * XS;
-    __shared__ __attribute__((aligned(16))) float xt_all[QW][XREG];
-    __shared__ __attribute__((aligned(16))) double yt_all[QW][QF * YH];
+    __shared__ __attribute__((aligned(16))) float xt_all[QW][2][QF * XS];
+    __shared__ __attribute__((aligned(16))) double yt_all[QW][QF * YS];
     if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int wave = threadIdx.x >> 6;
-    float* xe = xt_all[wave];                                   // extension phases: [QF][XS]
-    float* xm[2] = {xt_all[wave], xt_all[wave] + QF * XM};      // streaming: two buffers [QF][XM]
+    float (*xt)[QF * XS] = xt_all[wave];
     double* yt = yt_all[wave];
     const int lane = threadIdx.x & 63, u = lane / LPS, sub = lane % LPS;
     const int id = blockIdx.x * QW + wave;
@@ -402,23 +392,19 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
             pre[it] = p.rx[(size_t)fr * N + c];
         }
     };
-    auto store_ext = [&](int colofs) {                          // 64-column layout
+    auto store_chunk = [&](float* dst, int colofs) {
 #pragma unroll
-        for (int it = 0; it < LI; ++it) xe[(it * 2 + lrow) * XS + colofs + lcol] = pre[it];
-    };
-    auto store_chunk = [&](float* dst) {                        // 32-column layout
-#pragma unroll
-        for (int it = 0; it < LI; ++it) dst[(it * 2 + lrow) * XM + lcol] = pre[it];
+        for (int it = 0; it < LI; ++it) dst[(it * 2 + lrow) * XS + colofs + lcol] = pre[it];
     };
 
     double* fwd = p.fwd + ((size_t)(band * p.ntiles + tile) * NE) * QF + u;   // row i at fwd[i * QF]
     // every lane of a quad holds the same y after the broadcast and stores it to the same address: no divergence
 
     // ---- forward pass: left odd extension from x[0..P]
-    load_chunk(0);  store_ext(0);
-    load_chunk(CH); store_ext(CH);
+    load_chunk(0);  store_chunk(xt[0], 0);
+    load_chunk(CH); store_chunk(xt[0], CH);
     wave_sync();
-    const float* xr = xe + u * XS;
+    const float* xr = xt[0] + u * XS;
     {
         const float x0 = xr[0];
         init((double)(2.0f * x0 - xr[P]));
@@ -433,14 +419,14 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     wave_sync();
     // ---- forward pass: the frame, 32-sample chunks in registers, next chunk prefetched
     const int nfull = N / CH, ntail = N - nfull * CH;
-    load_chunk(0); store_chunk(xm[0]);
+    load_chunk(0); store_chunk(xt[0], 0);
     wave_sync();
 #pragma unroll 1
     for (int c = 0; c < nfull; ++c) {
         const int cur = c & 1;
         float xc[CH];
         {
-            const float4* src = reinterpret_cast<const float4*>(xm[cur] + u * XM);
+            const float4* src = reinterpret_cast<const float4*>(xt[cur] + u * XS);
 #pragma unroll
             for (int v = 0; v < CH / 4; ++v) {
                 const float4 t = src[v];
@@ -454,11 +440,11 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
             fwd[t * QF] = y;
         }
         fwd += CH * QF;
-        store_chunk(xm[cur ^ 1]);
+        store_chunk(xt[cur ^ 1], 0);
         wave_sync();
     }
     {
-        const float* xc = xm[nfull & 1] + u * XM;
+        const float* xc = xt[nfull & 1] + u * XS;
 #pragma unroll 1
         for (int t = 0; t < ntail; ++t) {
             const double y = f.step((double)xc[t]);
@@ -468,8 +454,8 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     }
     wave_sync();
     // ---- forward pass: right odd extension from x[N-64 .. N-1]
-    load_chunk(N - 64); store_ext(0);
-    load_chunk(N - 32); store_ext(CH);
+    load_chunk(N - 64); store_chunk(xt[0], 0);
+    load_chunk(N - 32); store_chunk(xt[0], CH);
     wave_sync();
     double ylast = 0.0;
     {
@@ -489,21 +475,17 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     // ---- backward pass, newest sample first; stops at the first frame sample (the rest is cropped)
     init(ylast);
     const double* bwd = fwd - QF;
-    double* yrow = yt + u * YH;
-    const int srow = lane >> 3, scol = (lane & 7) * 2;
-    constexpr int FI = QF / 8 > 0 ? QF / 8 : 1;
-    auto flush = [&](int n0) {          // tile columns [n0, n0+16) of the QF rows as 16-byte stores
+    double* yrow = yt + u * YS;
+    const int srow = lane >> 4, scol = (lane & 15) * 2;
+    auto flush = [&](int n0) {          // tile columns [n0, n0+32) of 16 rows as 16-byte stores
         wave_sync();
-        double2 v[FI];
+        double2 v[QF / 4];
 #pragma unroll
-        for (int it = 0; it < FI; ++it) {
-            const int r = it * 8 + srow;
-            v[it] = *reinterpret_cast<const double2*>(yt + (r < QF ? r : 0) * YH + scol);
-        }
+        for (int it = 0; it < QF / 4; ++it) v[it] = *reinterpret_cast<const double2*>(yt + (it * 4 + srow) * YS + scol);
 #pragma unroll
-        for (int it = 0; it < FI; ++it) {
-            const int r = it * 8 + srow, fr = f0 + r, n = n0 + scol;
-            if (r < QF && fr < p.B && n < N) {
+        for (int it = 0; it < QF / 4; ++it) {
+            const int fr = f0 + it * 4 + srow, n = n0 + scol;
+            if (fr < p.B && n < N) {
                 double* dst = p.y + ((size_t)fr * p.nb + band) * N + n;
                 if (p.y_aligned16 && n + 1 < N) *reinterpret_cast<double2*>(dst) = v[it];
                 else { dst[0] = v[it].x; if (n + 1 < N) dst[1] = v[it].y; }
@@ -513,21 +495,14 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     };
 #pragma unroll 1
     for (int k = 0; k < P; ++k) { (void)f.step(*bwd); bwd -= QF; }
-    if (ntail > HB) {
 #pragma unroll 1
-        for (int t = ntail - 1; t >= HB; --t) { const double y = f.step(*bwd); yrow[t - HB] = y; bwd -= QF; }
-        flush(nfull * CH + HB);
-    }
-    {
-        const int nt0 = ntail < HB ? ntail : HB;
-#pragma unroll 1
-        for (int t = nt0 - 1; t >= 0; --t) { const double y = f.step(*bwd); yrow[t] = y; bwd -= QF; }
-        if (nt0 > 0) flush(nfull * CH);
-    }
+    for (int t = ntail - 1; t >= 0; --t) { const double y = f.step(*bwd); yrow[t] = y; bwd -= QF; }
+    if (ntail > 0) flush(nfull * CH);
     // Full chunks.  The forward output comes back from HBM (the scratch is far larger than the caches), so rows are
     // requested two half-chunks (32 samples, about 2 us of arithmetic) before they are consumed: three register
     // buffers of 16 rows rotate through a loop unrolled by three.  Half-chunks keep the kernel at <= 184 registers,
     // which lets it share a SIMD with two workgroups' worth of band-kernel waves when it runs as a prefetch.
+    constexpr int HB = CH / 2;
     double bufA[HB], bufB[HB], bufC[HB];
     const double* row0 = bwd - (ptrdiff_t)(nfull * CH - 1) * QF;       // row of frame sample 0
     auto loadh = [&](double (&buf)[HB], int h) {                        // rows of half-chunk h, newest first; h < 0 clamps
@@ -536,9 +511,10 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
         for (int j = 0; j < HB; ++j) buf[j] = top[-(ptrdiff_t)j * QF];
     };
     auto runh = [&](const double (&buf)[HB], int h) {
+        double* dst = yrow + (h & 1) * HB;
 #pragma unroll
-        for (int j = 0; j < HB; ++j) yrow[HB - 1 - j] = f.step(buf[j]);
-        flush(h * HB);                                                  // 16 samples of every row
+        for (int j = 0; j < HB; ++j) dst[HB - 1 - j] = f.step(buf[j]);
+        if ((h & 1) == 0) flush((h >> 1) * CH);                         // lower half done: the 32-sample tile is complete
     };
     const int H = 2 * nfull;
     if (H > 0) { loadh(bufA, H - 1); loadh(bufB, H - 2); }
