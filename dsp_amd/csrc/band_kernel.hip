@@ -331,7 +331,14 @@ __global__ __launch_bounds__(kF9NT, 5) void band2_kernel(BandParams p, int B) {
         }
     }
     const int nz_lo = kstart, nz_hi = kstart + p.noise_n;   // evaluated exactly anyway
-    if (tid < 512) {
+    // A sample that is not finite (in either frame of the pair) spreads through the transform into every lag of both
+    // frames, and the bound is then NaN or infinite: nothing is known about either frame, and both get the overflowing
+    // list that makes the exact kernel evaluate every lag from the frame's own float64 signal -- a frame's record never
+    // depends on what its partner holds.
+    const bool unusable = !(eps < (double)INFINITY);
+    if (unusable) {
+        if (tid < 2) ncand[tid] = kB2MaxCand + 1;
+    } else if (tid < 512) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = tid + 512 * j, qd = k - p.half;

@@ -27,7 +27,8 @@
  *     ECHO_ERR_INVALID.
  *   - Samples are finite numbers (AudioIO.record delivers int16 / 2**15, airSonar_optimized.py:573).  Frames holding
  *     Inf or NaN are outside the contract: the zero-phase IIR then yields a different Inf/NaN pattern than
- *     scipy.signal.filtfilt (it evaluates z + 0 * y where SciPy evaluates z alone).
+ *     scipy.signal.filtfilt (it evaluates z + 0 * y where SciPy evaluates z alone), and the record of such a frame is
+ *     unspecified.  Every other frame of the batch is unaffected: a frame's results never depend on its neighbours.
  */
 #ifndef ECHO_HIP_H
 #define ECHO_HIP_H

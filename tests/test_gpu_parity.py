@@ -808,3 +808,30 @@ def test_disputed_long_chirp_indices():
             assert got != ref_index and margin < MARGIN_BOUND and noise < 1e-7
     for e in engines.values():
         e.close()
+
+
+@pytest.mark.parametrize("which,mode", [("optimized", "named"), ("optimized", "full"), ("realtime", "named"),
+                                        ("original", "named")])
+def test_a_non_finite_frame_leaves_its_neighbours_alone(which, mode):
+    """Samples that are not finite are outside the contract (the reference's frames are int16 / 2**15), but a frame that
+    holds one must not change any other frame of its batch: the pair kernel of the named chain transforms two frames
+    at once, so a NaN or Inf in one would spread into its partner's float32 correlation -- the kernel then hands both
+    frames to the all-lag float64 evaluation instead.  Records and spectra of every other frame are the bytes of the
+    clean batch, whichever half of a pair the bad frame sits in."""
+    from dsp_amd.engine import EchoEngine
+    cfg = {"optimized": lambda: C.optimized_config(C.BANDS_DISTINCT), "realtime": C.realtime_config,
+           "original": C.original_config}[which]()
+    e = EchoEngine(cfg)
+    rx = synth_frames(24, cfg, e.tables.tx_pcm, start=5)
+    clean_rec, clean_spec = e.chain(rx, mode=mode)
+    clean_rec, clean_spec = clean_rec.clone(), clean_spec.clone()
+    for bad, val in ((10, np.nan), (11, np.inf), (4, -np.inf), (23, np.nan)):
+        r2 = rx.copy(); r2[bad, cfg.n_rx // 2] = val
+        rec, spec = e.chain(r2, mode=mode)
+        torch.cuda.synchronize()
+        keep = torch.tensor([i for i in range(len(rx)) if i != bad], device=rec.device)
+        assert torch.equal(rec[keep], clean_rec[keep]), (bad, val)
+        assert torch.equal(spec[keep], clean_spec[keep]), (bad, val)
+    rec, _ = e.chain(rx, mode=mode)                              # and the engine is as good as before
+    assert torch.equal(rec, clean_rec)
+    e.close()
