@@ -28,10 +28,16 @@ struct GfftPlan {
     int root_off[kGfftMaxPass];  // offset of the pass's r roots exp(-2*pi*i*t/r) in the roots table
     int pairs[kGfftMaxPass];     // conjugate output pairs per work item (1..3), chosen for nt threads
     int per_lane[kGfftMaxPass];  // 1: items are (pair block, butterfly) per lane; 0: (pair block, 64 butterflies) per wavefront
+    int bfly[kGfftMaxPass];      // 1: the pass runs as in-register butterflies (radix <= kGfftMaxBfly), one per lane
     int nroots;
 };
+constexpr int kGfftMaxBfly = 10;
 
-inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512) {
+// merge_small: small prime factors are multiplied into radices of up to kGfftMaxBfly (3*3 -> 9, 2*5 -> 10, 2*2 -> 4 ...)
+// and every pass of such a radix runs as in-register butterflies -- fewer passes, each input read once, about half the
+// arithmetic of the r-term sums.  Off by default: the float64 transforms of the envelope branch keep the summation order
+// their parity runs were made with.
+inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512, bool merge_small = false) {
     pl.n = n; pl.npass = 0; pl.nroots = 0;
     if (n < 1) return false;
     int fac[32], nf = 0, rem = n;
@@ -40,9 +46,24 @@ inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512) {
     if (rem > 1) { if (nf == 32) return false; fac[nf++] = rem; }
     // merge pairs of 2 into 4 (fewer passes); then order by decreasing radix
     int twos = 0, out[32], no = 0;
+    if (merge_small) {
+        // largest factor first, each multiplied by the largest remaining factors that keep the product <= kGfftMaxBfly
+        bool used[32];
+        for (int i = 0; i < nf; ++i) used[i] = false;
+        for (int i = nf - 1; i >= 0; --i) {
+            if (used[i]) continue;
+            used[i] = true;
+            int prod = fac[i];
+            if (prod <= kGfftMaxBfly)
+                for (int j = i - 1; j >= 0; --j)
+                    if (!used[j] && prod * fac[j] <= kGfftMaxBfly) { prod *= fac[j]; used[j] = true; }
+            out[no++] = prod;
+        }
+    } else {
     for (int i = 0; i < nf; ++i) { if (fac[i] == 2) ++twos; else out[no++] = fac[i]; }
     for (; twos >= 2; twos -= 2) out[no++] = 4;
     if (twos) out[no++] = 2;
+    }
     for (int i = 0; i < no; ++i)
         for (int j = i + 1; j < no; ++j)
             if (out[j] > out[i]) { const int t = out[i]; out[i] = out[j]; out[j] = t; }
@@ -61,6 +82,7 @@ inline bool gfft_plan(GfftPlan& pl, int n, int nt = 512) {
             if (cost < best_cost) { best_cost = cost; best = P; }
         }
         pl.pairs[i] = best; pl.per_lane[i] = 0;
+        pl.bfly[i] = (merge_small && out[i] >= 2 && out[i] <= kGfftMaxBfly) ? 1 : 0;
         // few butterflies per pass (n/r well below a multiple of 64) leave lanes idle in the wavefront mapping:
         // then every lane takes its own (pair block, butterfly) and keeps its own root indices
         const int cols = n / out[i];
@@ -305,9 +327,123 @@ ECHO_HD void gfft_pass_lane(int tid, int nt, const GfftPlan& pl, int ps, const c
     }
 }
 
+// ---- small radices as in-register butterflies.
+// One lane per butterfly: the R inputs are read once, X[q] = sum_s v[s] W_R^(s q) is evaluated through the symmetric
+// halves t[s] = v[s] + v[R-s], u[s] = v[s] - v[R-s]:
+//   X[q], X[R-q] = (v[0] + sum_s cos(2 pi q s / R) t[s] (+ (-1)^q v[R/2])) -/+ i sum_s sin(2 pi q s / R) u[s]
+// (forward; the inverse transform swaps the pair).  The cosines and sines come from the pass's root table
+// (roots[k] = exp(-2 pi i k / R)), indexed at compile time.
+template <int R> struct GfftFold {                      // (q s) mod R folded into 1 .. R/2 with the signs of cos and sin
+    static constexpr int k(int q, int s) { return ((q * s) % R) <= R / 2 ? (q * s) % R : R - (q * s) % R; }
+    static constexpr bool neg_sin(int q, int s) { return ((q * s) % R) > R / 2; }
+};
+
+template <class T, int R>
+ECHO_HD void gfft_bfly(cpx<T> (&v)[R], const cpx<T>* roots, bool inv) {
+    constexpr int H = (R - 1) / 2;                      // conjugate pairs
+    constexpr bool even = R % 2 == 0;
+    T c[H + 1], sn[H + 1];
+#pragma unroll
+    for (int k = 1; k <= H; ++k) { c[k] = roots[k].x; sn[k] = -roots[k].y; }      // cos, sin of 2 pi k / R
+    cpx<T> t[H + 1], u[H + 1];
+#pragma unroll
+    for (int s = 1; s <= H; ++s) {
+        t[s] = cpx<T>{v[s].x + v[R - s].x, v[s].y + v[R - s].y};
+        u[s] = cpx<T>{v[s].x - v[R - s].x, v[s].y - v[R - s].y};
+    }
+    cpx<T> o[R];
+    o[0] = v[0];
+#pragma unroll
+    for (int s = 1; s <= H; ++s) { o[0].x += t[s].x; o[0].y += t[s].y; }
+    if (even) { o[0].x += v[R / 2].x; o[0].y += v[R / 2].y; }
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        cpx<T> P = v[0], Q{(T)0, (T)0};
+        if (even) {
+            if (q % 2) { P.x -= v[R / 2].x; P.y -= v[R / 2].y; } else { P.x += v[R / 2].x; P.y += v[R / 2].y; }
+        }
+#pragma unroll
+        for (int s = 1; s <= H; ++s) {
+            const int k = GfftFold<R>::k(q, s);
+            if (k == 0) {                               // q s is a multiple of R: cos = 1, sin = 0
+                P.x += t[s].x; P.y += t[s].y;
+                continue;
+            }
+            if (even && k == R / 2) {                   // cos = -1, sin = 0
+                P.x -= t[s].x; P.y -= t[s].y;
+                continue;
+            }
+            P.x = gf_fma(c[k], t[s].x, P.x); P.y = gf_fma(c[k], t[s].y, P.y);
+            if (GfftFold<R>::neg_sin(q, s)) { Q.x = gf_fma(-sn[k], u[s].x, Q.x); Q.y = gf_fma(-sn[k], u[s].y, Q.y); }
+            else                            { Q.x = gf_fma(sn[k], u[s].x, Q.x);  Q.y = gf_fma(sn[k], u[s].y, Q.y); }
+        }
+        // forward: X[q] = P - i Q, X[R-q] = P + i Q
+        const cpx<T> a{P.x + Q.y, P.y - Q.x}, b{P.x - Q.y, P.y + Q.x};
+        o[q] = inv ? b : a; o[R - q] = inv ? a : b;
+    }
+    if (even) {                                         // q = R/2: alternating sum
+        cpx<T> a = v[0];
+#pragma unroll
+        for (int s = 1; s <= H; ++s) {
+            if (s % 2) { a.x -= t[s].x; a.y -= t[s].y; } else { a.x += t[s].x; a.y += t[s].y; }
+        }
+        if ((R / 2) % 2) { a.x -= v[R / 2].x; a.y -= v[R / 2].y; } else { a.x += v[R / 2].x; a.y += v[R / 2].y; }
+        o[R / 2] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = o[q];
+}
+
+template <class T, int R>
+ECHO_HD void gfft_pass_bfly(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out,
+                            const cpx<T>* roots, const cpx<T>* wn, bool inv) {
+    const int Lp = pl.lp[ps], m = pl.n / (Lp * R), cols = Lp * m;
+    const bool last = ps + 1 >= pl.npass;
+    const int m2 = last ? 1 : pl.n / (pl.lp[ps + 1] * pl.radix[ps + 1]);
+    for (int c = tid; c < cols; c += nt) {
+        const int k = c / m, j = c - k * m;
+        const cpx<T>* src = in + k * (m * R) + j;
+        cpx<T> v[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) v[s] = src[s * m];
+        // the twiddles the next pass wants on the outputs (see gfft_pass_p), fetched before the arithmetic
+        const int s2m2 = last ? 0 : (j / m2) * m2;
+        cpx<T> tw[R];
+        if (!last) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) tw[q] = wn[s2m2 * (k + Lp * q)];
+        }
+        gfft_bfly<T, R>(v, roots, inv);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            cpx<T> a = v[q];
+            if (!last) {
+                const cpx<T> w = tw[q];
+                const T wy = inv ? -w.y : w.y;
+                a = cpx<T>{a.x * w.x - a.y * wy, a.x * wy + a.y * w.x};
+            }
+            out[(k + Lp * q) * m + j] = a;
+        }
+    }
+}
+
 template <class T>
 ECHO_HD void gfft_pass(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
                        const cpx<T>* wn, bool inv) {
+    if (pl.bfly[ps]) {
+        switch (pl.radix[ps]) {
+            case 2: gfft_pass_bfly<T, 2>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 3: gfft_pass_bfly<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 4: gfft_pass_bfly<T, 4>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 5: gfft_pass_bfly<T, 5>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 6: gfft_pass_bfly<T, 6>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 7: gfft_pass_bfly<T, 7>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 8: gfft_pass_bfly<T, 8>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 9: gfft_pass_bfly<T, 9>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            case 10: gfft_pass_bfly<T, 10>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
+            default: break;
+        }
+    }
     if (pl.per_lane[ps]) {
         switch (pl.pairs[ps]) {
             case 1: gfft_pass_lane<T, 1>(tid, nt, pl, ps, in, out, roots, wn, inv); break;

@@ -149,7 +149,7 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
     p.n2 = N / 2; p.nbins = N / 2 + 1;
     p.spec_odd = N % 2; p.sb_m = 0;
     if (!p.spec_odd) {
-        p.has_spec = gfft_plan(p.splan, p.n2, kLSpecNT) ? 1 : 0;
+        p.has_spec = gfft_plan(p.splan, p.n2, kLSpecNT, true) ? 1 : 0;   // small factors as in-register butterflies
         p.spec_smem = 2 * p.n2 * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
     } else {
         // outputs 0 .. nbins-1 from inputs 0 .. N-1: the chirp filter is needed at -(N-1) .. nbins-1
@@ -157,7 +157,7 @@ inline bool plan_long(LongParams& p, int N, int M, int K, int nb, int min_delay,
         for (int m = N + p.nbins - 1; m <= 2 * N + 64 && !p.has_spec; ++m) {
             int r = m;
             for (int f = 2; f <= 7; ++f) while (r % f == 0) r /= f;
-            if (r == 1 && gfft_plan(p.splan, m, kLSpecNT)) { p.has_spec = 1; p.sb_m = m; }
+            if (r == 1 && gfft_plan(p.splan, m, kLSpecNT, true)) { p.has_spec = 1; p.sb_m = m; }
         }
         p.spec_smem = 2 * p.sb_m * 8 + (p.has_spec ? p.splan.nroots * 8 : 0);
     }

@@ -202,9 +202,9 @@ extern "C" int emul_long_corr_fft(int N, int M, int K, int nb, const double* chi
 // Generic mixed-radix FFT (dsp_amd/csrc/gfft.h), thread by thread.  in/out: n interleaved (re, im) doubles.
 #include "../../dsp_amd/csrc/gfft.h"
 
-template <class T> static int run_gfft(int n, int inv, const double* in, double* out) {
+template <class T> static int run_gfft(int n, int inv, const double* in, double* out, bool merge_small = false) {
     GfftPlan pl;
-    if (!gfft_plan(pl, n)) return -2;
+    if (!gfft_plan(pl, n, 512, merge_small)) return -2;
     std::vector<cpx<T>> roots, wn, a(n), b(n);
     gfft_tables(pl, roots, wn);
     for (int i = 0; i < n; ++i) a[i] = cpx<T>{(T)in[2 * i], (T)in[2 * i + 1]};
@@ -221,6 +221,10 @@ template <class T> static int run_gfft(int n, int inv, const double* in, double*
 
 extern "C" int emul_gfft(int n, int inv, int use_float, const double* in, double* out) {
     return use_float ? run_gfft<float>(n, inv, in, out) : run_gfft<double>(n, inv, in, out);
+}
+// the same with small factors merged into in-register butterflies (what the spectrum kernels of long frames run)
+extern "C" int emul_gfft_bfly(int n, int inv, int use_float, const double* in, double* out) {
+    return use_float ? run_gfft<float>(n, inv, in, out, true) : run_gfft<double>(n, inv, in, out, true);
 }
 
 // Envelope branch for the correlation (dsp_amd/csrc/env_phases.h), thread by thread.

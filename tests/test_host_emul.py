@@ -258,6 +258,28 @@ def test_emulated_generic_fft():
                 assert np.abs(out[:, 0] + 1j * out[:, 1] - ref).max() <= tol * np.abs(ref).max()
 
 
+def test_emulated_fft_with_small_radix_butterflies():
+    """The same transform with the small prime factors merged into radices of up to 10 and every such pass run as
+    in-register butterflies (the plan of the long-frame spectrum kernels): every radix 2..10 alone and in products, the
+    lengths the kernels use (4410 = 10*9*7*7, 3600, the chirp-z lengths of odd frames), lengths that keep a large prime
+    factor as an r-term pass beside butterfly passes (2278 = 67*17*2), forward and inverse, float32 and float64."""
+    subprocess.check_call(["make", "-C", EMUL], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(EMUL, "libemul.so"))
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.emul_gfft_bfly.argtypes = [I, I, I, P, P]
+    rng = np.random.default_rng(1)
+    for n in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 35, 49, 81, 100, 210, 4410, 2205, 3600, 7200, 7203, 2278, 11 * 30, 1):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        xin = np.ascontiguousarray(np.stack([x.real, x.imag], -1))
+        for inv in (0, 1):
+            ref = np.fft.ifft(x) * n if inv else np.fft.fft(x)
+            for use_float, tol in ((0, 5e-15), (1, 1e-6)):
+                out = np.zeros((n, 2))
+                assert lib.emul_gfft_bfly(n, inv, use_float, _ptr(xin), _ptr(out)) > 0, n
+                err = np.abs(out[:, 0] + 1j * out[:, 1] - ref).max() / np.abs(ref).max()
+                assert err <= tol, (n, inv, use_float, err)
+
+
 def test_emulated_envelope_branch(emul, gold_default):
     """Correlation envelope branch (float64 Hilbert by mixed-radix FFT, uniform_filter1d(5), find_peaks with height,
     distance and prominence, peak choice, SNR, corr_quality) and the band-signal quality that rides on the spectrum
