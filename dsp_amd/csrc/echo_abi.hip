@@ -266,7 +266,7 @@ int run_iir(EchoHandle* h, const float* rx, double* y, int B, hipStream_t s, dou
         const long quad_waves = (long)p.nb * ((B + 15) / 16);
         const int lps = h->iir_lps ? h->iir_lps : ((quad_waves <= 192 && !corun) ? 16 : 4);
         p.ntiles = (B + 64 / lps - 1) / (64 / lps);
-        return launch_iir_quad(p, h->cfg.iir_ncoef, lps, s);
+        return launch_iir_quad(p, h->cfg.iir_ncoef, lps, h->bodd0, s);
     }
     p.ntiles = (B + 63) / 64;
     return launch_iir(p, h->cfg.iir_ncoef, h->bodd0, s);

@@ -47,7 +47,7 @@ struct KalmanParams {
 
 int launch_iir(const IirParams& p, int ncoef, bool bodd0, hipStream_t s);       // one lane per (frame, band), 64-frame tiles
 int iir_kernel_prepare();                                                          // raises the lane kernel's LDS limit
-int launch_iir_quad(const IirParams& p, int ncoef, int lps, hipStream_t s);    // lps lanes per (frame, band): 4 or 16; tiles of 64/lps frames
+int launch_iir_quad(const IirParams& p, int ncoef, int lps, bool bodd0, hipStream_t s);   // lps lanes per (frame, band): 4 or 16; tiles of 64/lps frames; bodd0: b[odd] == 0
 int launch_band(const BandParams& p, int B, hipStream_t s);
 int band_kernel_prepare(int smem_bytes, int spec_smem_bytes, int spec_hilb_smem_bytes);
 int band2_kernel_prepare(int smem_bytes, int exact_smem_bytes);

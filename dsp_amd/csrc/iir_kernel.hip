@@ -243,7 +243,10 @@ __device__ __forceinline__ double dpp_quad_next(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int NS>
+// BZ: the numerator's odd coefficients are exactly zero (a Butterworth band-pass) and NS is even, so that the states
+// with a zero coefficient sit in the same slots (j even <-> state index odd) of every lane: their x * 0 and the addition
+// of that zero are skipped (z + 0 == z), 4 of the 23 instructions per sample for NS = 4.
+template <int NS, bool BZ = false>
 struct Df2tQuad {
     double z[NS];
     double bl[NS], al[NS], b0;
@@ -272,11 +275,11 @@ struct Df2tQuad {
         double px[NS], t[NS];
         const double yb = b0 * x;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) px[j] = x * bl[j];
+        for (int j = 0; j < NS; ++j) px[j] = (BZ && j % 2 == 0) ? 0.0 : x * bl[j];
         const double zn = dpp_quad_next(z[0]);
         const double yc = z[0] + yb;
 #pragma unroll
-        for (int j = 0; j + 1 < NS; ++j) t[j] = z[j + 1] + px[j];
+        for (int j = 0; j + 1 < NS; ++j) t[j] = (BZ && j % 2 == 0) ? z[j + 1] : z[j + 1] + px[j];
         // zn * 1 + px rounds exactly as zn + px; the sub-lane without a next state multiplies by 0 instead of selecting
         t[NS - 1] = __builtin_fma(zn, keep, px[NS - 1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -343,18 +346,18 @@ constexpr int QW = 4;       // waves per workgroup: one per SIMD of the compute 
 // One-wave workgroups leave the choice of SIMD to the dispatcher, which was seen to stack two or three of these
 // latency-chains on one SIMD after some predecessors (0.79 ms instead of 0.59 ms per 4096 frames); a four-wave
 // workgroup is spread over the four SIMDs of its compute unit.
-template <int NC, int LPS> struct IirFilt;
-template <int NC> struct IirFilt<NC, 4> {
-    Df2tQuad<(NC - 1) / 4> f;
+template <int NC, int LPS, bool BZ> struct IirFilt;
+template <int NC, bool BZ> struct IirFilt<NC, 4, BZ> {
+    Df2tQuad<(NC - 1) / 4, BZ && ((NC - 1) / 4) % 2 == 0> f;
     __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) { f.template setup<NC>(p, band, sub); }
 };
-template <int NC> struct IirFilt<NC, 16> {
+template <int NC, bool BZ> struct IirFilt<NC, 16, BZ> {
     Df2tRow<NC> f;
     __device__ __forceinline__ void setup(const IirParams& p, int band, int sub) { f.setup(p, band, sub); }
 };
 
 // LPS lanes per (frame, band): 4 (quad mapping, 16 frames per wave) or 16 (row mapping, 4 frames per wave)
-template <int NC, int LPS>
+template <int NC, int LPS, bool BZ = false>
 __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p) {
     constexpr int QF = 64 / LPS;                // frames per wave
     __shared__ __attribute__((aligned(16))) float xt_all[QW][2][QF * XS];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64 * QW) void iir_filtfilt_quad_kernel(IirParams p)
     const int N = p.N, P = p.P, NE = N + 2 * P;
     const int f0 = tile * QF;
 
-    IirFilt<NC, LPS> filt;
+    IirFilt<NC, LPS, BZ> filt;
     filt.setup(p, band, sub);
     auto& f = filt.f;
     auto init = [&](double x0) { f.init(x0); };
@@ -532,12 +535,14 @@ template __global__ void iir_filtfilt_quad_kernel<13, 4>(IirParams);
 template __global__ void iir_filtfilt_quad_kernel<17, 4>(IirParams);
 template __global__ void iir_filtfilt_quad_kernel<13, 16>(IirParams);
 template __global__ void iir_filtfilt_quad_kernel<17, 16>(IirParams);
+template __global__ void iir_filtfilt_quad_kernel<17, 4, true>(IirParams);
 
 // p.ntiles = ceil(B / (64 / lps)) tiles of 64 / lps frames; lps = 4 or 16
-int launch_iir_quad(const IirParams& p, int ncoef, int lps, hipStream_t s) {
+int launch_iir_quad(const IirParams& p, int ncoef, int lps, bool bodd0, hipStream_t s) {
     const int groups = (p.ntiles + 7) / 8;
     dim3 grid(groups * 8 * p.nb / QW), block(64 * QW);
-    if (ncoef == 13 && lps == 4)       hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13, 4>), grid, block, 0, s, p);
+    if (ncoef == 17 && lps == 4 && bodd0) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17, 4, true>), grid, block, 0, s, p);
+    else if (ncoef == 13 && lps == 4)       hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13, 4>), grid, block, 0, s, p);
     else if (ncoef == 17 && lps == 4)  hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17, 4>), grid, block, 0, s, p);
     else if (ncoef == 13 && lps == 16) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<13, 16>), grid, block, 0, s, p);
     else if (ncoef == 17 && lps == 16) hipLaunchKernelGGL((iir_filtfilt_quad_kernel<17, 16>), grid, block, 0, s, p);
