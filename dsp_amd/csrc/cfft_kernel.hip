@@ -5,6 +5,7 @@
 #include "../../include/echo_hip.h"
 #include "echo_internal.h"
 #include "cfft_phases.h"
+#include "rcf_phases.h"
 
 namespace echo {
 
@@ -38,6 +39,80 @@ __global__ __launch_bounds__(kCfNT) void long_corr_tp_kernel(LongParams p) {
     ECHO_CF_TP_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kCfNT);
 #undef ECHO_PHASE
 #undef ECHO_SYNC
+}
+
+// The single real transform of rcf_phases.h with the detector behind it: the form the chain takes when its plan exists.
+__global__ __launch_bounds__(kRcNT) void long_rcorr_det_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_RC_DET_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kRcNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+__global__ __launch_bounds__(kRcNT) void long_rcorr_tp_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_RC_TP_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kRcNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+__global__ __launch_bounds__(kRcNT) void long_rcorr_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_RC_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kRcNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+static int rcf_smem(const LongParams& p) { return p.rc_smem + (kDetExtra > kCfTpExtra ? kDetExtra : kCfTpExtra); }
+
+int rcf_kernel_prepare(const LongParams& p) {
+    static_assert(kLDetNT <= kRcNT, "two-peak detector behind the transform");
+    if (!p.rc_use) return ECHO_OK;
+    if (rcf_smem(p) > 160 * 1024) return ECHO_ERR_INVALID;
+    const void* ks[] = {reinterpret_cast<const void*>(long_rcorr_det_kernel), reinterpret_cast<const void*>(long_rcorr_tp_kernel),
+                        reinterpret_cast<const void*>(long_rcorr_kernel)};
+    for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, rcf_smem(p)) != hipSuccess) return ECHO_ERR_HIP;
+    return ECHO_OK;
+}
+
+static bool rcf_ready(const LongParams& p) {
+    return p.rc_use && p.rc_wh && p.rc_wk && p.rc_roots && p.rc_g && p.rc_pos && p.rc_k0 == p.k_begin &&
+           2 * p.rc_H >= p.L - p.k_begin + p.M - 1;
+}
+
+// true when launch_long_rcorr_det can replace launch_long_corr + launch_long_detect for these parameters
+bool long_rcorr_det_fits(const LongParams& p) {
+    if (!rcf_ready(p)) return false;
+    if (p.detector == ECHO_DET_MAD) return p.L - p.half > p.min_delay && p.k_begin == p.half + p.min_delay;
+    return p.detector == ECHO_DET_TWOPEAK && p.k_begin == 0 && p.L - p.half > 0;
+}
+
+int launch_long_rcorr_det(const LongParams& q, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    LongParams p = q;
+    if (!long_rcorr_det_fits(p) || !p.res_out) return ECHO_ERR_INVALID;
+    p.det_view = 2; p.det_q0 = p.k_begin - p.half; p.det_lds_off = p.rc_smem;
+    if (p.detector == ECHO_DET_TWOPEAK) hipLaunchKernelGGL(long_rcorr_tp_kernel, dim3(B * p.nb), dim3(kRcNT), rcf_smem(p), s, p);
+    else hipLaunchKernelGGL(long_rcorr_det_kernel, dim3(B * p.nb), dim3(kRcNT), rcf_smem(p), s, p);
+    return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
+}
+
+// lags [k_begin, L) to corr_out (the layout of launch_long_corr_fft)
+int launch_long_rcorr(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!rcf_ready(p) || !p.corr_out) return ECHO_ERR_INVALID;
+    hipLaunchKernelGGL(long_rcorr_kernel, dim3(B * p.nb), dim3(kRcNT), rcf_smem(p), s, p);
+    return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
 }
 
 int cfft_kernel_prepare() {

@@ -75,6 +75,8 @@ struct EchoHandle {
     cpx<float> *d_lbw = nullptr, *d_lbhat = nullptr;                       // long path, odd N: chirp factors and filter spectrum
     double2* d_dftw = nullptr;             // long path, frame lengths no FFT kernel holds: the N roots of unity of the direct sums
     cpx<double> *d_cfg = nullptr, *d_cfw2 = nullptr, *d_cftw = nullptr;   // long path: FFT matched filter tables
+    cpx<double> *d_rcwh = nullptr, *d_rcwk = nullptr, *d_rcroots = nullptr, *d_rcg = nullptr;   // the same as one real transform
+    int* d_rcpos = nullptr;
     // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_ready[2] = {nullptr, nullptr}, pf_consumed[2] = {nullptr, nullptr}, pf_t0 = nullptr, pf_t1 = nullptr;
@@ -535,6 +537,24 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_cftw, tw.data(), tw.size()));
             h->lbase.cf_g = h->d_cfg; h->lbase.cf_w2 = h->d_cfw2; h->lbase.cf_tw = h->d_cftw;
             if (rc == ECHO_OK) rc = cfft_kernel_prepare();
+            // the detectors that read one contiguous lag range take the matched filter as a single real transform
+            const char* rcf = std::getenv("ECHO_RCF");
+            const int det = cfg->detector;
+            if ((!rcf || std::atoi(rcf) != 0) && (det == ECHO_DET_MAD || det == ECHO_DET_TWOPEAK) &&
+                (det != ECHO_DET_MAD || h->lbase.L - h->lbase.half > h->lbase.min_delay) &&
+                plan_rcf(h->lbase, det == ECHO_DET_MAD ? h->lbase.half + h->lbase.min_delay : 0)) {
+                std::vector<zd> wh, wk, rr, rg;
+                std::vector<int> pos;
+                rcf_tables(h->lbase, nb, cfg->chirps, wh, wk, rr, rg, pos);
+                up(dev_upload(&h->d_rcwh, wh.data(), wh.size()));
+                up(dev_upload(&h->d_rcwk, wk.data(), wk.size()));
+                up(dev_upload(&h->d_rcroots, rr.data(), rr.size()));
+                up(dev_upload(&h->d_rcg, rg.data(), rg.size()));
+                up(dev_upload(&h->d_rcpos, pos.data(), pos.size()));
+                h->lbase.rc_wh = h->d_rcwh; h->lbase.rc_wk = h->d_rcwk; h->lbase.rc_roots = h->d_rcroots;
+                h->lbase.rc_g = h->d_rcg; h->lbase.rc_pos = h->d_rcpos;
+                if (rc == ECHO_OK) rc = rcf_kernel_prepare(h->lbase);
+            }
         }
         if (rc == ECHO_OK) rc = long_kernels_prepare(h->lbase);
     }
@@ -594,7 +614,8 @@ void echo_destroy(EchoHandle* h) {
     free_scratch(h);
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
-                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw};
+                    h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw,
+                    h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
@@ -1168,10 +1189,12 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             q.k_begin = all_lags ? 0 : std::min(q.half + q.min_delay, q.L - 1);
             q.corr_k0 = all_lags ? 0 : q.half; q.corr_stride = all_lags ? q.L : q.L - q.half;
             q.det_io = sc.pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = sc.res;
-            if (h->fuse_det && long_corr_det_fits(q)) {
+            if (h->fuse_det && long_rcorr_det_fits(q)) {
+                rc = launch_long_rcorr_det(q, n, s);        // one real transform; the correlation stays in the workgroup
+            } else if (h->fuse_det && long_corr_det_fits(q)) {
                 rc = launch_long_corr_det(q, n, s);         // the correlation stays in the workgroup that detects on it
             } else {
-                rc = launch_long_corr(q, n, s);
+                rc = long_rcorr_det_fits(q) ? launch_long_rcorr(q, n, s) : launch_long_corr(q, n, s);
                 if (rc) return rc;
                 rc = launch_long_detect(q, n, s);
             }

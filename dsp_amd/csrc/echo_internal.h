@@ -62,6 +62,11 @@ int cfft_kernel_prepare();
 int launch_long_corr_fft(const LongParams& p, int B, hipStream_t s);
 bool long_corr_det_fits(const LongParams& p);
 int launch_long_corr_det(const LongParams& p, int B, hipStream_t s);
+// the same as one real transform per (frame, band) (rcf_phases.h), when LongParams::rc_use
+int rcf_kernel_prepare(const LongParams& p);
+bool long_rcorr_det_fits(const LongParams& p);
+int launch_long_rcorr_det(const LongParams& p, int B, hipStream_t s);
+int launch_long_rcorr(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
 int launch_long_spec(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);

@@ -64,6 +64,8 @@ constexpr int kLSpecNT = 512;                  // threads per spectrum workgroup
 constexpr int kLPad = 64 * kR + 2 * kR;        // zero margin either side of the LDS signal: one wavefront's spread of
                                                // first outputs (64*kR) plus the window prefetch (2*kR)
 
+constexpr int kRcMaxPass = 6;                  // passes of the real-transform matched filter (rcf_phases.h)
+
 struct LongParams {
     int N, M, L, half, nb, K, min_delay, detector;
     int kgroups, mgroups, ypad;
@@ -93,7 +95,16 @@ struct LongParams {
     // filter's transform, finished in place (cfft_phases.h), holds it: pos[q] for q >= det_q0 is component w of complex
     // slot i + i/8, with q - det_q0 = w * cf_V + i; below det_q0 lies the blind zone (zero).  det_lds_off: byte offset
     // of the histograms and scalars behind pos.
+    // det_view 2: the single real transform of rcf_phases.h holds it: q - det_q0 = 2 i + w, component w of slot i + i/8.
     int det_view, det_q0, det_lds_off;
+    // matched filter as one real cyclic correlation (rcf_phases.h), chosen where every wanted lag fits one transform
+    int rc_use, rc_H, rc_npass, rc_k0, rc_smem;
+    int rc_radix[kRcMaxPass], rc_root_off[kRcMaxPass];
+    const cpx<double>* rc_wh;        // [H] exp(-2 pi i e / H)
+    const cpx<double>* rc_wk;        // [H/2 + 1] exp(-2 pi i k / 2H)
+    const cpx<double>* rc_roots;     // per pass the r roots of unity
+    const cpx<double>* rc_g;         // [nb][H + 1] conj(DFT_2H(chirp)) / H
+    const int* rc_pos;               // [H] position of frequency k after the forward passes
     BandRes* res_out;                // [B][nb]
     // spectrum: rfft of the N-sample band signal as a packed complex FFT of length N/2 (gfft.h), float32
     int has_spec, n2, nbins, spec_db;
@@ -400,6 +411,7 @@ ECHO_HD double det_read(const LongParams& p, const unsigned char* smem, int q) {
     if (!p.det_view) return d[q];
     const int j = q - p.det_q0;
     if (j < 0) return 0.0;
+    if (p.det_view == 2) { const int i = j >> 1; return d[2 * (i + (i >> 3)) + (j & 1)]; }
     const int w = j >= p.cf_V ? 1 : 0, i = j - (w ? p.cf_V : 0);
     return d[2 * (i + (i >> 3)) + w];
 }

@@ -199,6 +199,44 @@ extern "C" int emul_long_corr_fft(int N, int M, int K, int nb, const double* chi
     return cf_pairs(p);
 }
 
+// Matched filter of long frames as one real cyclic correlation (dsp_amd/csrc/rcf_phases.h), thread by thread: corr[k],
+// k_begin <= k < L, written to corr_out[blk * L + k].  Returns the packed transform length H, or < 0 when the plan
+// does not apply.  with_detector != 0: the median/MAD detector (detector 1) or the two-peak detector (3) of the chain runs
+// on the transform's LDS layout instead of the store, results into peak / snr / amp.
+#include "../../dsp_amd/csrc/rcf_phases.h"
+extern "C" int emul_long_rcorr(int N, int M, int K, int nb, const double* chirps, const double* band, int B, int k_begin,
+                               int nt, double* corr_out, int detector, int min_delay, int noise_n, double gate,
+                               int* peak, double* snr, double* amp, int* valid) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, min_delay, detector ? detector : 1)) return -2;
+    if (!plan_rcf(p, k_begin)) return -3;
+    std::vector<zd> wh, wk, roots, g;
+    std::vector<int> pos;
+    rcf_tables(p, nb, chirps, wh, wk, roots, g, pos);
+    p.rc_wh = wh.data(); p.rc_wk = wk.data(); p.rc_roots = roots.data(); p.rc_g = g.data(); p.rc_pos = pos.data();
+    p.band_in = band; p.corr_out = corr_out; p.k_begin = k_begin; p.corr_k0 = 0; p.corr_stride = p.L;
+    p.noise_n = noise_n; p.snr_gate = gate;
+    std::vector<BandRes> res((size_t)B * nb);
+    p.res_out = res.data();
+    p.det_view = 2; p.det_q0 = k_begin - p.half; p.det_lds_off = p.rc_smem;
+    std::vector<unsigned char> smem(p.rc_smem + (kDetExtra > kCfTpExtra ? kDetExtra : kCfTpExtra) + 64);
+    unsigned char* s = smem.data();
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        if (detector == 1) { ECHO_RC_DET_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
+        else if (detector == 3) { ECHO_RC_TP_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
+        else { ECHO_RC_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
+    }
+#undef PHASE
+#undef SYNC
+    if (detector)
+        for (size_t i = 0; i < res.size(); ++i) { peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude; valid[i] = res[i].pad; }
+    return p.rc_H;
+}
+
 // Generic mixed-radix FFT (dsp_amd/csrc/gfft.h), thread by thread.  in/out: n interleaved (re, im) doubles.
 #include "../../dsp_amd/csrc/gfft.h"
 

@@ -419,7 +419,21 @@ def test_long_chain_detects_inside_the_matched_filter_kernel(which, monkeypatch)
     b, spec_b = apart.chain(rxs, n_streams=1, kalman=BatchedKalman(apart, 1), want_spectra=True)
     assert torch.equal(a, b) and torch.equal(spec_a, spec_b)
     assert _rec(a)["valid_mask"].any()
-    fused.close(); apart.close()
+    # both run the matched filter as one real transform per band; the two-sub-block transform it replaced
+    # (ECHO_RCF=0) computes the same correlation to rounding: same echoes, floats to 1e-9
+    monkeypatch.setenv("ECHO_RCF", "0")
+    blocks = _engine(cfg)
+    monkeypatch.delenv("ECHO_RCF")
+    c, spec_c = blocks.chain(rxs, n_streams=1, kalman=BatchedKalman(blocks, 1), want_spectra=True)
+    ra, rc = _rec(a), _rec(c)
+    assert torch.equal(spec_a, spec_c)
+    for k in ra.dtype.names:
+        x, y = np.asarray(ra[k]), np.asarray(rc[k])
+        if x.dtype.kind == "f":
+            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=k)
+        else:
+            assert np.array_equal(x, y), k
+    fused.close(); apart.close(); blocks.close()
 
 
 @pytest.mark.parametrize("n_rx", [8820, 8822])

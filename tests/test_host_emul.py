@@ -241,6 +241,62 @@ def test_emulated_fft_matched_filter(emul, gold_original):
     assert (np.abs(corr[0] - ref) / np.abs(ref).max(axis=-1, keepdims=True)).max() <= 1e-7
 
 
+def test_emulated_real_transform_matched_filter(emul):
+    """Matched filter of long frames as one real cyclic correlation (rcf_phases.h), thread by thread: every lag from
+    k_begin on against the exact direct sum (np.correlate in float64), lags below k_begin untouched; then the MAD and
+    two-peak detectors run in the same workgroup on the packed layout against the oracle's detectors applied to those
+    very correlation values (indices exact, SNR to 1e-12)."""
+    from oracle import echo_oracle as O
+    P, I, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    emul.emul_long_rcorr.argtypes = [I, I, I, I, P, P, I, I, I, P, I, I, I, D, P, P, P, P]
+    rng = np.random.default_rng(11)
+    fs = 48000
+    # (N, M, detector, min_delay): airSonar.py's sizes (MAD detector, lags from half + min_delay), 666.py's (two-peak,
+    # every lag), and two small ones with other radices
+    for N, M, det, min_delay, nt in ((8820, 4410, 1, 500, 768), (7200, 2400, 3, 0, 768), (3000, 600, 1, 37, 512),
+                                     (2000, 700, 3, 0, 512)):
+        nb, B, L = 2, 2, N + M - 1
+        half = L // 2
+        k_begin = half + min_delay if det == 1 else 0
+        chirps = np.ascontiguousarray(rng.standard_normal((nb, M)))
+        band = np.ascontiguousarray(rng.standard_normal((B, nb, N)) * 1e-2)
+        e0 = N // 2 + 300
+
+        def echo(b, j, at, gain):
+            n = min(M, N - at)
+            band[b, j, at:at + n] += gain * chirps[j][:n]
+
+        echo(0, 0, e0, 0.8)                                          # one echo
+        echo(0, 1, e0, 0.8); echo(0, 1, e0 + N // 10, 0.5)          # two
+        band[1, 1] = 0.0                                             # silence
+        corr = np.full((B, nb, L), np.nan)
+        peak = np.zeros((B, nb), np.int32); snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); valid = np.zeros((B, nb), np.int32)
+        H = emul.emul_long_rcorr(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, nt, _ptr(corr), 0, min_delay, 0,
+                                 6.0, None, None, None, None)
+        assert H > 0 and 2 * H >= L - k_begin + M - 1
+        for b in range(B):
+            for j in range(nb):
+                ref = np.correlate(band[b, j], chirps[j], "full")
+                assert np.isnan(corr[b, j, :k_begin]).all()
+                assert np.abs(corr[b, j, k_begin:] - ref[k_begin:]).max() <= 4e-15 * max(np.abs(ref).max(), 1e-300)
+        noise_n = int((L - half) * 0.2)
+        assert emul.emul_long_rcorr(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, nt, None, det, min_delay,
+                                    noise_n, 6.0, _ptr(peak), _ptr(snr), _ptr(amp), _ptr(valid)) == H
+        for b in range(B):
+            for j in range(nb):
+                c = np.where(np.isnan(corr[b, j]), 0.0, corr[b, j])
+                if det == 1:
+                    want = O.first_strong_peak_mad(c, fs, min_delay)
+                    assert peak[b, j] == (-1 if want is None else want), (N, b, j, peak[b, j], want)
+                else:
+                    want, want_snr = O.first_strong_peak_twopeak(c, fs)
+                    assert bool(valid[b, j]) == (want is not None), (N, b, j, peak[b, j], want)
+                    if want is not None:
+                        assert peak[b, j] == want
+                    np.testing.assert_allclose(snr[b, j], want_snr, rtol=1e-12, atol=1e-12)
+                    np.testing.assert_allclose(amp[b, j], np.abs(c).max(), rtol=0, atol=0)
+
+
 def test_emulated_generic_fft():
     subprocess.check_call(["make", "-C", EMUL], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(os.path.join(EMUL, "libemul.so"))
