@@ -41,8 +41,14 @@ __global__ __launch_bounds__(kCfNT) void long_corr_tp_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
+#ifdef ECHO_RC_VGPR
+#define ECHO_RC_ATTR __attribute__((amdgpu_num_vgpr(ECHO_RC_VGPR)))
+#else
+#define ECHO_RC_ATTR
+#endif
+
 // The single real transform of rcf_phases.h with the detector behind it: the form the chain takes when its plan exists.
-__global__ __launch_bounds__(kRcNT) void long_rcorr_det_kernel(LongParams p) {
+__global__ __launch_bounds__(kRcNT) ECHO_RC_ATTR void long_rcorr_det_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
 #define ECHO_PHASE(...) { __VA_ARGS__; }
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(kRcNT) void long_rcorr_det_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
-__global__ __launch_bounds__(kRcNT) void long_rcorr_tp_kernel(LongParams p) {
+__global__ __launch_bounds__(kRcNT) ECHO_RC_ATTR void long_rcorr_tp_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
 #define ECHO_PHASE(...) { __VA_ARGS__; }
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(kRcNT) void long_rcorr_tp_kernel(LongParams p) {
 #undef ECHO_SYNC
 }
 
-__global__ __launch_bounds__(kRcNT) void long_rcorr_kernel(LongParams p) {
+__global__ __launch_bounds__(kRcNT) ECHO_RC_ATTR void long_rcorr_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
 #define ECHO_PHASE(...) { __VA_ARGS__; }

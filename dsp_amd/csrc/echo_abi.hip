@@ -281,7 +281,13 @@ int ensure_prefetch(EchoHandle* h, int frames) {
         // prefetched IIR waits (in its high-priority queue) for events of the caller's normal-priority stream, which in
         // turn waits for a collective queued at normal priority, and that collective was never scheduled.  Callers that
         // want the prefetch stream on a queue of its own issue their first prefetch before they initialise RCCL.
-        if (hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
+        int pf_cus = 0;
+        if (const char* m = std::getenv("ECHO_PF_CUS")) pf_cus = std::atoi(m);    // experiment: the prefetched IIR on a subset of the compute units
+        if (pf_cus > 0) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < pf_cus && i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&h->pf_stream, 8, mask) != hipSuccess) return ECHO_ERR_HIP;
+        } else if (hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking) != hipSuccess) return ECHO_ERR_HIP;
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&h->pf_ready[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->pf_consumed[i], hipEventDisableTiming) != hipSuccess) return ECHO_ERR_HIP;
@@ -537,10 +543,12 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_cftw, tw.data(), tw.size()));
             h->lbase.cf_g = h->d_cfg; h->lbase.cf_w2 = h->d_cfw2; h->lbase.cf_tw = h->d_cftw;
             if (rc == ECHO_OK) rc = cfft_kernel_prepare();
-            // the detectors that read one contiguous lag range take the matched filter as a single real transform
+            // ECHO_RCF=1: the detectors that read one contiguous lag range take the matched filter as a single real
+            // transform (rcf_phases.h).  Fewer points and 50 KB less LDS, yet slower on gfx950 than the power-of-two
+            // transform above (its radix-10/9/6 passes cost more than they save), so it is not the default.
             const char* rcf = std::getenv("ECHO_RCF");
             const int det = cfg->detector;
-            if ((!rcf || std::atoi(rcf) != 0) && (det == ECHO_DET_MAD || det == ECHO_DET_TWOPEAK) &&
+            if (rcf && std::atoi(rcf) != 0 && (det == ECHO_DET_MAD || det == ECHO_DET_TWOPEAK) &&
                 (det != ECHO_DET_MAD || h->lbase.L - h->lbase.half > h->lbase.min_delay) &&
                 plan_rcf(h->lbase, det == ECHO_DET_MAD ? h->lbase.half + h->lbase.min_delay : 0)) {
                 std::vector<zd> wh, wk, rr, rg;

@@ -427,10 +427,12 @@ ECHO_HD void gfft_pass_bfly(int tid, int nt, const GfftPlan& pl, int ps, const c
     }
 }
 
-template <class T>
+// BFLY: the kernel's plans may hold butterfly passes (planned with merge_small).  A kernel whose plans never do leaves
+// it off: the nine butterfly bodies would only raise its register allocation (the float64 envelope kernel spilled).
+template <class T, bool BFLY = false>
 ECHO_HD void gfft_pass(int tid, int nt, const GfftPlan& pl, int ps, const cpx<T>* in, cpx<T>* out, const cpx<T>* roots,
                        const cpx<T>* wn, bool inv) {
-    if (pl.bfly[ps]) {
+    if (BFLY && pl.bfly[ps]) {
         switch (pl.radix[ps]) {
             case 2: gfft_pass_bfly<T, 2>(tid, nt, pl, ps, in, out, roots, wn, inv); return;
             case 3: gfft_pass_bfly<T, 3>(tid, nt, pl, ps, in, out, roots, wn, inv); return;

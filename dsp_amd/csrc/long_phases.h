@@ -99,8 +99,8 @@ struct LongParams {
     int det_view, det_q0, det_lds_off;
     // matched filter as one real cyclic correlation (rcf_phases.h), chosen where every wanted lag fits one transform
     int rc_use, rc_H, rc_npass, rc_k0, rc_smem;
-    int rc_radix[kRcMaxPass], rc_root_off[kRcMaxPass];
-    const cpx<double>* rc_wh;        // [H] exp(-2 pi i e / H)
+    int rc_radix[kRcMaxPass], rc_root_off[kRcMaxPass], rc_tw_off[kRcMaxPass];
+    const cpx<double>* rc_wh;        // pass twiddles: per pass the runs exp(-2 pi i (i m) / S), m = 1..r-1, i < S / r
     const cpx<double>* rc_wk;        // [H/2 + 1] exp(-2 pi i k / 2H)
     const cpx<double>* rc_roots;     // per pass the r roots of unity
     const cpx<double>* rc_g;         // [nb][H + 1] conj(DFT_2H(chirp)) / H
@@ -191,7 +191,7 @@ ECHO_HD void ph_lspec_load(int tid, int nt, int blk, const LongParams& p, unsign
 ECHO_HD void ph_lspec_pass(int tid, int nt, const LongParams& p, unsigned char* smem, int ps, int src) {
     cpx<float>* b0 = reinterpret_cast<cpx<float>*>(smem);
     const cpx<float>* r = b0 + 2 * p.n2 + p.splan.root_off[ps];
-    gfft_pass<float>(tid, nt, p.splan, ps, b0 + (src ? p.n2 : 0), b0 + (src ? 0 : p.n2), r, p.swn, false);
+    gfft_pass<float, true>(tid, nt, p.splan, ps, b0 + (src ? p.n2 : 0), b0 + (src ? 0 : p.n2), r, p.swn, false);
 }
 ECHO_HD void ph_lspec_store(int tid, int nt, int blk, const LongParams& p, unsigned char* smem, int which) {
     const cpx<float>* Z = reinterpret_cast<const cpx<float>*>(smem) + (which ? p.n2 : 0);
@@ -226,7 +226,7 @@ ECHO_HD void ph_lspec_odd_load(int tid, int nt, int blk, const LongParams& p, un
 ECHO_HD void ph_lspec_odd_pass(int tid, int nt, const LongParams& p, unsigned char* smem, int ps, int src, bool inv) {
     cpx<float>* b0 = reinterpret_cast<cpx<float>*>(smem);
     const cpx<float>* r = b0 + 2 * p.sb_m + p.splan.root_off[ps];
-    gfft_pass<float>(tid, nt, p.splan, ps, b0 + (src ? p.sb_m : 0), b0 + (src ? 0 : p.sb_m), r, p.swn, inv);
+    gfft_pass<float, true>(tid, nt, p.splan, ps, b0 + (src ? p.sb_m : 0), b0 + (src ? 0 : p.sb_m), r, p.swn, inv);
 }
 ECHO_HD void ph_lspec_odd_mul(int tid, int nt, const LongParams& p, unsigned char* smem, int which) {
     cpx<float>* z = reinterpret_cast<cpx<float>*>(smem) + (which ? p.sb_m : 0);
@@ -634,9 +634,9 @@ ECHO_HD void ph_fs_hist(int tid, int nt, const LongParams& p, unsigned char* sme
 ECHO_HD void ph_fs_scan_a(int tid, int nt, const LongParams& p, unsigned char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int* fh = det_fhist(p, smem);
-    const int per = kFsBins / nt;
+    const int per = (kFsBins + nt - 1) / nt;                 // nt need not divide the number of bins
     int c = 0;
-    for (int e = 0; e < per; ++e) c += fh[tid * per + e];
+    for (int e = 0; e < per; ++e) c += tid * per + e < kFsBins ? fh[tid * per + e] : 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((tid & 63) == 0) det_wtot(p, smem)[tid >> 6] = c;
 #endif
@@ -650,9 +650,9 @@ ECHO_HD void ph_fs_scan_b(int tid, int nt, const LongParams& p, unsigned char* s
     DetMisc* m = det_misc(p, smem);
     const int* fh = det_fhist(p, smem);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int per = kFsBins / nt, lane = tid & 63, wave = tid >> 6;
+    const int per = (kFsBins + nt - 1) / nt, lane = tid & 63, wave = tid >> 6;
     int c = 0;
-    for (int e = 0; e < per; ++e) c += fh[tid * per + e];
+    for (int e = 0; e < per; ++e) c += tid * per + e < kFsBins ? fh[tid * per + e] : 0;
     int inc = c;
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
     const int* wt = det_wtot(p, smem);
@@ -660,7 +660,7 @@ ECHO_HD void ph_fs_scan_b(int tid, int nt, const LongParams& p, unsigned char* s
     for (int w = 0; w < wave; ++w) exc += wt[w];
     if (exc <= rank && rank < exc + c) {                    // one thread
         int cum = exc;
-        for (int e = 0; e < per; ++e) {
+        for (int e = 0; e < per && tid * per + e < kFsBins; ++e) {
             const int h = fh[tid * per + e];
             if (rank < cum + h) { fs_chosen(m, tid * per + e, cum, h); break; }
             cum += h;

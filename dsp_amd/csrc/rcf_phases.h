@@ -24,7 +24,10 @@
 
 namespace echo {
 
-constexpr int kRcNT = 768;                        // threads per workgroup
+#ifndef ECHO_RC_NT
+#define ECHO_RC_NT 768
+#endif
+constexpr int kRcNT = ECHO_RC_NT;                 // threads per workgroup
 
 // smallest H >= hmin that is a product of radices <= kGfftMaxBfly in at most kRcMaxPass passes; 0 if none below hmax
 inline bool rc_factor(int H, int* radix, int* npass) {
@@ -93,14 +96,25 @@ inline void fft_smooth(std::vector<std::complex<long double>>& a) {
     }
 }
 
-// Tables: wh[e] = exp(-2 pi i e / H); wk[k] = exp(-2 pi i k / 2H), k <= H/2; roots[root_off[p] + t] = exp(-2 pi i t / r_p);
+// Tables: wh = the pass twiddles, for pass ps with block size S, radix r, stride q = S / r the runs
+// wh[tw_off[ps] + (m - 1) * q + i] = exp(-2 pi i (i m) / S), 1 <= m < r, i < q (one coalesced read per m);
+// wk[k] = exp(-2 pi i k / 2H), k <= H/2; roots[root_off[p] + t] = exp(-2 pi i t / r_p);
 // g[band][k] = conj(DFT_2H(chirp_band))[k] / H, k <= H; pos[k] = position of frequency k after the forward passes.
-inline void rcf_tables(const LongParams& p, int nb, const double* chirps, std::vector<zd>& wh, std::vector<zd>& wk,
+inline void rcf_tables(LongParams& p, int nb, const double* chirps, std::vector<zd>& wh, std::vector<zd>& wk,
                        std::vector<zd>& roots, std::vector<zd>& g, std::vector<int>& pos) {
     const long double tau = 6.283185307179586476925286766559005768L;
     const int H = p.rc_H, F2 = 2 * H;
-    wh.resize(H); wk.resize(H / 2 + 1);
-    for (int e = 0; e < H; ++e) wh[e] = zmk((double)cosl(-tau * e / H), (double)sinl(-tau * e / H));
+    wh.clear(); wk.resize(H / 2 + 1);
+    for (int ps = 0, S = H; ps < p.rc_npass; ++ps) {
+        const int r = p.rc_radix[ps], q = S / r;
+        p.rc_tw_off[ps] = (int)wh.size();
+        for (int m = 1; m < r; ++m)
+            for (int i = 0; i < q; ++i) {
+                const long double a = -tau * (long double)((long)i * m % S) / (long double)S;
+                wh.push_back(zmk((double)cosl(a), (double)sinl(a)));
+            }
+        S = q;
+    }
     for (int k = 0; k <= H / 2; ++k) wk[k] = zmk((double)cosl(-tau * k / F2), (double)sinl(-tau * k / F2));
     roots.clear();
     for (int ps = 0; ps < p.rc_npass; ++ps)
@@ -132,16 +146,16 @@ ECHO_HD void ph_rc_load(int tid, int nt, int blk, const LongParams& p, unsigned 
 }
 
 // One in-place pass of radix R on blocks of S elements (stride q = S / R).  Forward: butterfly, then output m times
-// W_S^(i m); inverse: the conjugate twiddles first, then the conjugate butterfly.  W_S^(i m) = wh[i m (H / S)].
+// W_S^(i m); inverse: the conjugate twiddles first, then the conjugate butterfly.  W_S^(i m) = tw[(m - 1) q + i].
 template <int R, bool INV>
-ECHO_HD void rc_pass(int tid, int nt, int S, const zd* roots, const LongParams& p, unsigned char* smem) {
+ECHO_HD void rc_pass(int tid, int nt, int S, const zd* roots, const zd* tw, const LongParams& p, unsigned char* smem) {
     zd* f = reinterpret_cast<zd*>(smem);
-    const int q = S / R, scale = p.rc_H / S;
+    const int q = S / R;
     for (int t = tid; t < p.rc_H / R; t += nt) {
         const int b = t / q, i = t - b * q, base = b * S + i;
         zd v[R], w[R];
 #pragma unroll
-        for (int m = 1; m < R; ++m) w[m] = p.rc_wh[i * m * scale];
+        for (int m = 1; m < R; ++m) w[m] = tw[(m - 1) * q + i];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = f[zpos(base + j * q)];
         if (INV) {
@@ -163,16 +177,17 @@ ECHO_HD void ph_rc_pass(int tid, int nt, int ps, const LongParams& p, unsigned c
     int S = p.rc_H;
     for (int i = 0; i < ps; ++i) S /= p.rc_radix[i];
     const zd* roots = p.rc_roots + p.rc_root_off[ps];
+    const zd* tw = p.rc_wh + p.rc_tw_off[ps];
     switch (p.rc_radix[ps]) {
-        case 2: rc_pass<2, INV>(tid, nt, S, roots, p, smem); break;
-        case 3: rc_pass<3, INV>(tid, nt, S, roots, p, smem); break;
-        case 4: rc_pass<4, INV>(tid, nt, S, roots, p, smem); break;
-        case 5: rc_pass<5, INV>(tid, nt, S, roots, p, smem); break;
-        case 6: rc_pass<6, INV>(tid, nt, S, roots, p, smem); break;
-        case 7: rc_pass<7, INV>(tid, nt, S, roots, p, smem); break;
-        case 8: rc_pass<8, INV>(tid, nt, S, roots, p, smem); break;
-        case 9: rc_pass<9, INV>(tid, nt, S, roots, p, smem); break;
-        case 10: rc_pass<10, INV>(tid, nt, S, roots, p, smem); break;
+        case 2: rc_pass<2, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 3: rc_pass<3, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 4: rc_pass<4, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 5: rc_pass<5, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 6: rc_pass<6, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 7: rc_pass<7, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 8: rc_pass<8, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 9: rc_pass<9, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 10: rc_pass<10, INV>(tid, nt, S, roots, tw, p, smem); break;
         default: break;
     }
 }

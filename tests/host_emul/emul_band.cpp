@@ -250,7 +250,7 @@ template <class T> static int run_gfft(int n, int inv, const double* in, double*
     const int nt = 512;
     for (int ps = 0; ps < pl.npass; ++ps) {
         for (int tid = 0; tid < nt; ++tid)
-            gfft_pass<T>(tid, nt, pl, ps, src, dst, roots.data() + pl.root_off[ps], wn.data(), inv != 0);
+            gfft_pass<T, true>(tid, nt, pl, ps, src, dst, roots.data() + pl.root_off[ps], wn.data(), inv != 0);
         std::swap(src, dst);
     }
     for (int i = 0; i < n; ++i) { out[2 * i] = src[i].x; out[2 * i + 1] = src[i].y; }
