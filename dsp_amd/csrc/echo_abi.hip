@@ -115,8 +115,10 @@ struct EchoHandle {
     int iir_mode = 0;                      // 0 = choose by batch size, 1 = lane per (frame, band), 2 = quad per (frame, band)
     int iir_lps = 0;                       // lanes per sequence in the quad kernel: 0 = choose, 4 or 16 (ECHO_IIR_LPS)
     int iir_prio = 0;                      // wave priority of the quad IIR kernel (ECHO_IIR_PRIO, experiments)
-    int iir_side = 0;                      // ECHO_IIR_SIDE=1: the chain's IIR runs on one stream shared by every handle
-                                           // of the device (ECHO_IIR_CUS=n: created with a mask of n compute units)
+    // The chain's IIR on a stream shared by every handle of the device and confined to iir_cus compute units (0: all).
+    // iir_side: 0 never, 1 always (ECHO_IIR_SIDE), 2 when the call is one pass of at least iir_side_min frames and a batch of
+    // another handle is still in flight on the device (the default for long frames).
+    int iir_side = 0, iir_cus = 0, iir_side_min = 2048;
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
@@ -138,23 +140,46 @@ struct EchoHandle {
 
 namespace {
 
-// Experiment: one stream per device on which the IIRs of every handle run one after the other, optionally confined
-// to a subset of the compute units.
+// One stream per (device, number of compute units) on which the IIRs of every handle run one after the other, confined
+// to that many compute units (0: all of them).  The mask takes the first n bits: the driver deals mask bits round-robin
+// over the XCDs and their shader engines, so a multiple of 32 is an even share of every engine (others measured slower).
 std::mutex g_side_mu;
-hipStream_t g_side_stream[kMaxDevices];
-hipStream_t side_stream(int device) {
+struct SideStream { int ncu; hipStream_t st; };
+std::vector<SideStream> g_side_streams[kMaxDevices];
+hipStream_t side_stream(int device, int ncu) {
     std::lock_guard<std::mutex> guard(g_side_mu);
-    if (g_side_stream[device]) return g_side_stream[device];
+    for (const SideStream& e : g_side_streams[device]) if (e.ncu == ncu) return e.st;
     hipStream_t st = nullptr;
-    int ncu = 0;
-    if (const char* m = std::getenv("ECHO_IIR_CUS")) ncu = std::atoi(m);
     if (ncu > 0) {
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < ncu && i < 256; ++i) mask[i / 32] |= 1u << (i % 32);
         if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) return nullptr;
     } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    g_side_stream[device] = st;
+    g_side_streams[device].push_back(SideStream{ncu, st});
     return st;
+}
+
+// Batches in flight: per device, an event at the end of the latest chain pass of each of the last few handles.  The
+// events belong to this table, not to the handles, which come and go.  Guarded by g_side_mu.
+struct InFlight { const void* who; hipEvent_t done; bool set; };
+constexpr int kInFlight = 4;
+InFlight g_inflight[kMaxDevices][kInFlight];
+int g_inflight_next[kMaxDevices];
+
+bool others_in_flight(const EchoHandle* h) {
+    std::lock_guard<std::mutex> guard(g_side_mu);
+    for (const InFlight& e : g_inflight[h->device])
+        if (e.set && e.who != h && hipEventQuery(e.done) == hipErrorNotReady) return true;
+    return false;
+}
+void note_in_flight(const EchoHandle* h, hipStream_t s) {
+    std::lock_guard<std::mutex> guard(g_side_mu);
+    InFlight* slot = nullptr;
+    for (InFlight& e : g_inflight[h->device]) if (e.who == h) slot = &e;
+    if (!slot) { slot = &g_inflight[h->device][g_inflight_next[h->device]]; g_inflight_next[h->device] = (g_inflight_next[h->device] + 1) % kInFlight; }
+    if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) { slot->done = nullptr; slot->set = false; return; }
+    slot->who = h;
+    slot->set = hipEventRecord(slot->done, s) == hipSuccess;
 }
 
 template <class T> int dev_upload(T** dst, const T* src, size_t n) {
@@ -429,7 +454,6 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     if (const char* m = std::getenv("ECHO_LANES")) h->self_lanes = std::atoi(m);
     if (const char* m = std::getenv("ECHO_FUSE_DET")) h->fuse_det = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_PRIO")) h->iir_prio = std::atoi(m);
-    if (const char* m = std::getenv("ECHO_IIR_SIDE")) h->iir_side = std::atoi(m);
     if (const char* m = std::getenv("ECHO_IIR_LPS")) { const int v = std::atoi(m); h->iir_lps = (v == 4 || v == 16) ? v : 0; }
     (void)hipGetDevice(&h->device);
     // device address of this GPU's copy of the static scratch array, looked up once per device
@@ -463,6 +487,23 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             if (cfg->detector == ECHO_DET_MEDIAN || cfg->detector == ECHO_DET_MEANPOW) h->lbase.noise_n = nn;
         }
     }
+    if (h->long_path) {
+        // Every other kernel of the long-frame chain fills the LDS of a compute unit, so a unit that holds an IIR
+        // workgroup (51 KB, one wave per SIMD, 1.1 ms of a latency-bound recurrence) is closed to them: batches in flight
+        // on several streams then overlap the IIR with nothing, it merely holds 192 of the 256 units.  Confined to half of
+        // the units its workgroups stack (two or three per unit, the recurrence hardly slower) and the other half stays
+        // with the matched filter, FIR and spectrum kernels of the other batches: airSonar.py's set 1.21 -> 1.34 M
+        // frames/s, 666.py's 1.30 -> 1.44 M under three lanes.
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        // A batch alone on the device gains nothing from it (its IIR has nothing to make room for and runs 1.8 instead of
+        // 1.1 ms), and small batches lose to the two extra event hops: hence the in-flight test and the size floor.
+        h->iir_cus = (ncu / 2) / 32 * 32;
+        h->iir_side = h->iir_cus > 0 ? 2 : 0;
+    }
+    if (const char* m = std::getenv("ECHO_IIR_SIDE")) h->iir_side = std::atoi(m) ? 1 : 0;   // overrides, experiments
+    if (const char* m = std::getenv("ECHO_IIR_CUS")) h->iir_cus = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("ECHO_IIR_SIDE_MIN")) h->iir_side_min = std::max(0, std::atoi(m));
     const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
     h->bodd0 = true;
     for (int j = 0; j < nb; ++j)
@@ -1164,6 +1205,15 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         const double* y_in = sc.y;
         if (!ext && (f0 == 0 || inner)) h->pf_valid = false;   // consumed or discarded (a caller-scratch call leaves it alone)
         const int pre_slot = h->pf_slot;
+        bool use_side = false, track = false;
+        if (!pre && h->iir_side && !ext && !h->capturing) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool plain = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+            track = plain && h->iir_side == 2;
+            // single-pass calls only: a second pass's IIR must wait for the first pass's readers of the scratch, and that
+            // wait at the head of the shared stream would hold up the other handles' IIRs queued behind it
+            use_side = plain && (h->iir_side == 1 || (n == B && n >= h->iir_side_min && others_in_flight(h)));
+        }
         if (pre) {
             if (hipStreamWaitEvent(s, h->pf_ready[pre_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
             y_in = h->pf_y[pre_slot];
@@ -1172,8 +1222,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 if (rc) return rc;
                 h->pf_valid = false;
             }
-        } else if (h->iir_side && !ext && !h->capturing) {
-            hipStream_t side = side_stream(h->device);
+        } else if (use_side) {
+            hipStream_t side = side_stream(h->device, h->iir_cus);
             if (!side) return ECHO_ERR_HIP;
             if (!h->side_fork && (hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming) != hipSuccess ||
                                   hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming) != hipSuccess)) return ECHO_ERR_HIP;
@@ -1279,6 +1329,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             rc = launch_kalman(k, s);
             if (rc) return rc;
         }
+        if (track) note_in_flight(h, s);
         if (prof) {
             (void)hipEventRecord(ev[4], s);
             if ((int)h->prof_pair.size() <= h->prof_used) h->prof_pair.resize(h->prof_used + 1);

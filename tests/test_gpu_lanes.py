@@ -127,3 +127,38 @@ def test_scheduling_switches_leave_the_bytes_alone(env, monkeypatch):
         assert torch.equal(outs[i], want[i][0]) and torch.equal(specs[i], want[i][1]), i
     assert torch.equal(kal2.x, kal.x)
     ln.close(); eng.close(); plain.close()
+
+
+@pytest.mark.parametrize("which", ["original", "twopeak"])
+def test_long_frame_lanes_with_the_confined_iir_stream(which, monkeypatch):
+    """Long frames (airSonar.py's and 666.py's sizes): with batches of 2048 frames and more in flight on several
+    handles the library moves every IIR to one stream confined to half of the compute units.  Where the IIR runs
+    changes nothing in what is computed: the lanes' bytes equal those of an engine with that switched off
+    (ECHO_IIR_SIDE=0) called batch after batch."""
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    from dsp_amd.lanes import ChainLanes
+    cfg = C.original_config() if which == "original" else C.twopeak_config()
+    monkeypatch.setenv("ECHO_IIR_SIDE", "0")
+    plain = EchoEngine(cfg)
+    monkeypatch.delenv("ECHO_IIR_SIDE")
+    S, sizes = 64, [2048, 2560, 2048, 3072, 2048, 1024]
+    rx = plain.synth_frames(sum(sizes), first_frame=900)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    kal = BatchedKalman(plain, S)
+    want = [tuple(t.clone() for t in plain.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal)) for i in range(len(sizes))]
+    eng = EchoEngine(cfg)
+    ln = ChainLanes(eng, 3)
+    kal2 = BatchedKalman(eng, S)
+    outs = [torch.empty((n, 64), dtype=torch.uint8, device="cuda") for n in sizes]
+    specs = [torch.empty((n, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device="cuda") for n in sizes]
+    for rounds in range(2):                                  # the second round starts with batches already in flight
+        for i in range(len(sizes)):
+            ln.submit(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal2 if rounds == 0 else None, out=outs[i],
+                      spec_out=specs[i])
+        ln.join(); torch.cuda.synchronize()
+        for i in range(len(sizes)):
+            if rounds == 0:
+                assert torch.equal(outs[i], want[i][0]), i
+            assert torch.equal(specs[i], want[i][1]), i
+    assert torch.equal(kal2.x, kal.x)
+    ln.close(); eng.close(); plain.close()

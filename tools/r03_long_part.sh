@@ -13,7 +13,8 @@ d=json.loads(open("gpurun_out/r03/part/%s.json"%sys.argv[1]).read().strip().spli
 print(sys.argv[1], "%.3f M"%(d["value"]/1e6), "ms/step %.3f"%d["ms_per_step"], {k: round(v,3) for k,v in d["kernel_ms"].items()})
 PY
 }
-for cus in 96 128 160 192; do run orig_cu$cus ECHO_IIR_SIDE=1 ECHO_IIR_CUS=$cus -- --workload original || exit 1; done
-for cus in 96 128; do run orig_pf_cu$cus ECHO_PF_CUS=$cus -- --workload original --lanes 1 || exit 1; done
-for cus in 0 64 96 128; do run full_pf_cu$cus ECHO_PF_CUS=$cus -- --mode full --lanes 1 || exit 1; done
-for cus in 0 96 128; do run named_pf_cu$cus ECHO_PF_CUS=$cus -- --lanes 1 || exit 1; done
+run orig_l3_own ECHO_IIR_SIDE_OWN=1 -- --workload original &&
+run orig_l3_2048_own ECHO_IIR_SIDE_OWN=1 -- --workload original --frames 2048 &&
+run orig_l3_8192_own ECHO_IIR_SIDE_OWN=1 -- --workload original --frames 8192 --steps 100 &&
+run orig_l3_8192_own96 ECHO_IIR_SIDE_OWN=1 ECHO_IIR_CUS=96 -- --workload original --frames 8192 --steps 100 &&
+run tp_l3_own ECHO_IIR_SIDE_OWN=1 -- --workload twopeak
