@@ -19,7 +19,7 @@ EXPORTS = [
     "echo_set_profiling", "echo_last_kernel_ms", "echo_chain_noalloc", "echo_noalloc_max_frames",
     "echo_spectrum_rows", "echo_xcorr", "echo_envelope_rows", "echo_band_confidence", "echo_normalize_confidences",
     "echo_kalman_update_qr", "echo_chain_wave", "echo_kernel_times", "echo_chain_ordered", "echo_set_profiling_every",
-    "echo_first_strong_peak_rows", "echo_spectrum_any",
+    "echo_first_strong_peak_rows", "echo_spectrum_any", "echo_confined_iir_passes",
 ]
 
 
@@ -81,6 +81,8 @@ def load():
     lib.echo_chain_ordered.argtypes = [P, P, P, P, P, P, P, I, I, I, P, P, P]
     lib.echo_set_profiling_every.argtypes = [P, I, I]
     lib.echo_kernel_times.argtypes = [P, C.POINTER(C.c_float), I]
+    lib.echo_confined_iir_passes.argtypes = [P]
+    lib.echo_confined_iir_passes.restype = C.c_longlong
     lib.echo_chain_wave.argtypes = [P, P, P, P, P, P, P, P, P, I, I, P]
     lib.echo_chain_noalloc.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.echo_noalloc_max_frames.argtypes = [P]

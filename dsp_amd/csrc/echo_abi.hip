@@ -119,6 +119,8 @@ struct EchoHandle {
     // iir_side: 0 never, 1 always (ECHO_IIR_SIDE), 2 when the call is one pass of at least iir_side_min frames and a batch of
     // another handle is still in flight on the device (the default for long frames).
     int iir_side = 0, iir_cus = 0, iir_side_min = 2048;
+    int iir_side_full = 0, iir_cus_full = 0;   // the same for echo_chain_full calls of short-frame handles
+    long long side_passes = 0;             // passes whose IIR ran on that stream (echo_confined_iir_passes)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
@@ -501,8 +503,17 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
         h->iir_cus = (ncu / 2) / 32 * 32;
         h->iir_side = h->iir_cus > 0 ? 2 : 0;
     }
-    if (const char* m = std::getenv("ECHO_IIR_SIDE")) h->iir_side = std::atoi(m) ? 1 : 0;   // overrides, experiments
-    if (const char* m = std::getenv("ECHO_IIR_CUS")) h->iir_cus = std::max(0, std::atoi(m));
+    else {
+        // The full chain's envelope kernel fills a unit's LDS too (two buffers of 4341 complex doubles); its IIR is the
+        // shorter order-6 one, and an eighth of the units (one per shader engine) is the share that paid: 1.02 -> 1.10 M
+        // frames/s under three lanes (a quarter and more: no gain).
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        h->iir_cus_full = (ncu / 8) / 32 * 32;
+        h->iir_side_full = h->iir_cus_full > 0 ? 2 : 0;
+    }
+    if (const char* m = std::getenv("ECHO_IIR_SIDE")) h->iir_side = h->iir_side_full = std::atoi(m) ? 1 : 0;   // overrides, experiments
+    if (const char* m = std::getenv("ECHO_IIR_CUS")) h->iir_cus = h->iir_cus_full = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("ECHO_IIR_SIDE_MIN")) h->iir_side_min = std::max(0, std::atoi(m));
     const int nb = cfg->n_bands, nc = cfg->iir_ncoef;
     h->bodd0 = true;
@@ -732,6 +743,14 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
     if (fuse_ms) *fuse_ms = (float)(acc[3] / n);
     h->prof_used = 0;
     return ECHO_OK;
+}
+
+long long echo_confined_iir_passes(EchoHandle* h) {
+    if (!h) return -1;
+    ECHO_LOCK(h);
+    long long n = h->side_passes;
+    for (const EchoHandle* c : h->lane_clone) if (c) n += c->side_passes;
+    return n;
 }
 
 int echo_kernel_times(EchoHandle* h, float* ms, int n) {
@@ -1206,13 +1225,15 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         if (!ext && (f0 == 0 || inner)) h->pf_valid = false;   // consumed or discarded (a caller-scratch call leaves it alone)
         const int pre_slot = h->pf_slot;
         bool use_side = false, track = false;
-        if (!pre && h->iir_side && !ext && !h->capturing) {
+        const int side_mode = (full && !h->long_path) ? h->iir_side_full : h->iir_side;
+        const int side_cus = (full && !h->long_path) ? h->iir_cus_full : h->iir_cus;
+        if (!pre && side_mode && !ext && !h->capturing) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool plain = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-            track = plain && h->iir_side == 2;
+            track = plain && side_mode == 2;
             // single-pass calls only: a second pass's IIR must wait for the first pass's readers of the scratch, and that
             // wait at the head of the shared stream would hold up the other handles' IIRs queued behind it
-            use_side = plain && (h->iir_side == 1 || (n == B && n >= h->iir_side_min && others_in_flight(h)));
+            use_side = plain && (side_mode == 1 || (n == B && n >= h->iir_side_min && others_in_flight(h)));
         }
         if (pre) {
             if (hipStreamWaitEvent(s, h->pf_ready[pre_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
@@ -1223,10 +1244,11 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 h->pf_valid = false;
             }
         } else if (use_side) {
-            hipStream_t side = side_stream(h->device, h->iir_cus);
+            hipStream_t side = side_stream(h->device, side_cus);
             if (!side) return ECHO_ERR_HIP;
             if (!h->side_fork && (hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming) != hipSuccess ||
                                   hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming) != hipSuccess)) return ECHO_ERR_HIP;
+            ++h->side_passes;
             std::lock_guard<std::mutex> guard(g_side_mu);
             if (hipEventRecord(h->side_fork, s) != hipSuccess || hipStreamWaitEvent(side, h->side_fork, 0) != hipSuccess) return ECHO_ERR_HIP;
             rc = run_iir(h, rx + (size_t)f0 * N, sc.y, n, side, sc.fwd);
@@ -1376,7 +1398,7 @@ static EchoHandle* clone_for_lane(const EchoHandle* h) {
     for (int i = 0; i < 3; ++i) { c->lane_stream[i] = nullptr; c->lane_join[i] = nullptr; c->lane_kal[i] = nullptr; }
     c->lane_fork = nullptr; c->lanes_ready = false;
     c->last_stream = nullptr; c->last_stream_set = false; c->xs_event = nullptr;
-    c->side_fork = nullptr; c->side_join = nullptr;
+    c->side_fork = nullptr; c->side_join = nullptr; c->side_passes = 0;
     return c;
 }
 

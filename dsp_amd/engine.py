@@ -424,6 +424,12 @@ class EchoEngine:
         self._call("echo_kernel_times", self._h, ms, 6)
         return dict(zip(("iir", "band", "spec", "fuse", "pair", "exact"), (float(x) for x in ms)))
 
+    def confined_iir_passes(self) -> int:
+        """Passes of this engine whose IIR ran on the device's shared stream confined to a share of the compute units
+        (what the library does by itself for long frames and the full chain while other engines' batches are in
+        flight).  A scheduling diagnostic: results do not depend on it."""
+        return int(self.lib.echo_confined_iir_passes(self._h))
+
 
 class ChainGraph:
     """A recorded chain call (HIP graph) over fixed device buffers; see EchoEngine.capture_chain."""

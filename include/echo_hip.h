@@ -340,6 +340,12 @@ int echo_last_kernel_ms(EchoHandle* h, float* iir_ms, float* band_ms, float* spe
  * spectrum, fusion(+Kalman), pair kernel (float32 matched filter), exact kernel (float64 re-evaluation); the last two
  * are 0 when the band stage is the single-frame kernel.  Entries beyond 5 are set to 0. */
 int echo_kernel_times(EchoHandle* h, float* ms, int n);
+/* Scheduling diagnostic, no counterpart in the reference: the number of internal passes of this handle (its internal
+ * lanes included) whose IIR ran on the device's shared, compute-unit-confined stream since echo_create.  The library
+ * takes that route by itself for long-frame configurations and for echo_chain_full when the call is one pass of at
+ * least 2048 frames and a batch of another handle is still in flight on the device; results do not depend on it.
+ * -1 for a null handle. */
+long long echo_confined_iir_passes(EchoHandle* h);
 
 #ifdef __cplusplus
 }

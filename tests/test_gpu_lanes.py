@@ -129,15 +129,15 @@ def test_scheduling_switches_leave_the_bytes_alone(env, monkeypatch):
     ln.close(); eng.close(); plain.close()
 
 
-@pytest.mark.parametrize("which", ["original", "twopeak"])
-def test_long_frame_lanes_with_the_confined_iir_stream(which, monkeypatch):
-    """Long frames (airSonar.py's and 666.py's sizes): with batches of 2048 frames and more in flight on several
-    handles the library moves every IIR to one stream confined to half of the compute units.  Where the IIR runs
-    changes nothing in what is computed: the lanes' bytes equal those of an engine with that switched off
-    (ECHO_IIR_SIDE=0) called batch after batch."""
+@pytest.mark.parametrize("which,mode", [("original", "named"), ("twopeak", "named"), ("optimized", "full")])
+def test_lanes_with_the_confined_iir_stream(which, mode, monkeypatch):
+    """Long frames (airSonar.py's and 666.py's sizes) and the full chain of the short ones: with batches of 2048 frames
+    and more in flight on several handles the library moves every IIR to one stream confined to a share of the compute
+    units.  Where the IIR runs changes nothing in what is computed: the lanes' bytes equal those of an engine with that
+    switched off (ECHO_IIR_SIDE=0) called batch after batch."""
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.lanes import ChainLanes
-    cfg = C.original_config() if which == "original" else C.twopeak_config()
+    cfg = {"original": C.original_config, "twopeak": C.twopeak_config, "optimized": C.optimized_config}[which]()
     monkeypatch.setenv("ECHO_IIR_SIDE", "0")
     plain = EchoEngine(cfg)
     monkeypatch.delenv("ECHO_IIR_SIDE")
@@ -145,7 +145,8 @@ def test_long_frame_lanes_with_the_confined_iir_stream(which, monkeypatch):
     rx = plain.synth_frames(sum(sizes), first_frame=900)
     offs = np.concatenate([[0], np.cumsum(sizes)])
     kal = BatchedKalman(plain, S)
-    want = [tuple(t.clone() for t in plain.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal)) for i in range(len(sizes))]
+    want = [tuple(t.clone() for t in plain.chain(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal, mode=mode))
+            for i in range(len(sizes))]
     eng = EchoEngine(cfg)
     ln = ChainLanes(eng, 3)
     kal2 = BatchedKalman(eng, S)
@@ -154,11 +155,14 @@ def test_long_frame_lanes_with_the_confined_iir_stream(which, monkeypatch):
     for rounds in range(2):                                  # the second round starts with batches already in flight
         for i in range(len(sizes)):
             ln.submit(rx[offs[i]:offs[i + 1]], n_streams=S, kalman=kal2 if rounds == 0 else None, out=outs[i],
-                      spec_out=specs[i])
+                      spec_out=specs[i], mode=mode)
         ln.join(); torch.cuda.synchronize()
         for i in range(len(sizes)):
             if rounds == 0:
                 assert torch.equal(outs[i], want[i][0]), i
             assert torch.equal(specs[i], want[i][1]), i
     assert torch.equal(kal2.x, kal.x)
+    # the route was taken (by the lanes' engines, for batches of 2048 frames and more) and only there
+    assert sum(e.confined_iir_passes() for e in ln.engines) >= 4
+    assert plain.confined_iir_passes() == 0
     ln.close(); eng.close(); plain.close()

@@ -13,8 +13,9 @@ d=json.loads(open("gpurun_out/r03/part/%s.json"%sys.argv[1]).read().strip().spli
 print(sys.argv[1], "%.3f M"%(d["value"]/1e6), "ms/step %.3f"%d["ms_per_step"], {k: round(v,3) for k,v in d["kernel_ms"].items()})
 PY
 }
-run orig_l3_own ECHO_IIR_SIDE_OWN=1 -- --workload original &&
-run orig_l3_2048_own ECHO_IIR_SIDE_OWN=1 -- --workload original --frames 2048 &&
-run orig_l3_8192_own ECHO_IIR_SIDE_OWN=1 -- --workload original --frames 8192 --steps 100 &&
-run orig_l3_8192_own96 ECHO_IIR_SIDE_OWN=1 ECHO_IIR_CUS=96 -- --workload original --frames 8192 --steps 100 &&
-run tp_l3_own ECHO_IIR_SIDE_OWN=1 -- --workload twopeak
+run named_l3 X=1 -- &&
+run full_l3 X=1 -- --mode full &&
+run full_l3_forced ECHO_IIR_SIDE=1 ECHO_IIR_CUS=32 -- --mode full &&
+run full_l3_off ECHO_IIR_SIDE=0 -- --mode full &&
+run full_l1 X=1 -- --mode full --lanes 1 &&
+run orig_l3 X=1 -- --workload original
