@@ -68,12 +68,14 @@ __global__ __launch_bounds__(kRcNT) ECHO_RC_ATTR void long_rcorr_tp_kernel(LongP
 #undef ECHO_SYNC
 }
 
-__global__ __launch_bounds__(kRcNT) ECHO_RC_ATTR void long_rcorr_kernel(LongParams p) {
+// The transform alone, one workgroup per block of lags: small enough (LDS, registers) for two workgroups to share a
+// compute unit, so that one's barriers and memory waits are covered by the other's arithmetic.
+__global__ __launch_bounds__(kRcSplitNT, 4) void long_rcorr_kernel(LongParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int tid = threadIdx.x, sub = blockIdx.x, blk = blockIdx.y;
 #define ECHO_PHASE(...) { __VA_ARGS__; }
 #define ECHO_SYNC __syncthreads();
-    ECHO_RC_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kRcNT);
+    ECHO_RC_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, sub, blk, kRcSplitNT, kRcSplitMaxR);
 #undef ECHO_PHASE
 #undef ECHO_SYNC
 }
@@ -83,22 +85,31 @@ static int rcf_smem(const LongParams& p) { return p.rc_smem + (kDetExtra > kCfTp
 int rcf_kernel_prepare(const LongParams& p) {
     static_assert(kLDetNT <= kRcNT, "two-peak detector behind the transform");
     if (!p.rc_use) return ECHO_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(long_rcorr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            p.rc_smem) != hipSuccess) return ECHO_ERR_HIP;
+    if (p.rc_nblk != 1) return ECHO_OK;
     if (rcf_smem(p) > 160 * 1024) return ECHO_ERR_INVALID;
-    const void* ks[] = {reinterpret_cast<const void*>(long_rcorr_det_kernel), reinterpret_cast<const void*>(long_rcorr_tp_kernel),
-                        reinterpret_cast<const void*>(long_rcorr_kernel)};
+    const void* ks[] = {reinterpret_cast<const void*>(long_rcorr_det_kernel), reinterpret_cast<const void*>(long_rcorr_tp_kernel)};
     for (const void* k : ks)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, rcf_smem(p)) != hipSuccess) return ECHO_ERR_HIP;
     return ECHO_OK;
 }
 
 static bool rcf_ready(const LongParams& p) {
-    return p.rc_use && p.rc_wh && p.rc_wk && p.rc_roots && p.rc_g && p.rc_pos && p.rc_k0 == p.k_begin &&
-           2 * p.rc_H >= p.L - p.k_begin + p.M - 1;
+    return p.rc_use && p.rc_wh && p.rc_wk && p.rc_roots && p.rc_g && p.rc_pos && p.rc_k0 == p.k_begin && p.rc_nblk >= 1 &&
+           2 * p.rc_H >= p.rc_V + p.M - 1 && (long)p.rc_nblk * p.rc_V >= p.L - p.k_begin;
+}
+
+// true when launch_long_rcorr can replace launch_long_corr for these parameters
+// (the stand-alone kernel holds the butterflies up to radix kRcSplitMaxR only)
+bool long_rcorr_fits(const LongParams& p) {
+    for (int i = 0; i < p.rc_npass; ++i) if (p.rc_radix[i] > kRcSplitMaxR) return false;
+    return rcf_ready(p);
 }
 
 // true when launch_long_rcorr_det can replace launch_long_corr + launch_long_detect for these parameters
 bool long_rcorr_det_fits(const LongParams& p) {
-    if (!rcf_ready(p)) return false;
+    if (!rcf_ready(p) || p.rc_nblk != 1) return false;
     if (p.detector == ECHO_DET_MAD) return p.L - p.half > p.min_delay && p.k_begin == p.half + p.min_delay;
     return p.detector == ECHO_DET_TWOPEAK && p.k_begin == 0 && p.L - p.half > 0;
 }
@@ -116,8 +127,8 @@ int launch_long_rcorr_det(const LongParams& q, int B, hipStream_t s) {
 // lags [k_begin, L) to corr_out (the layout of launch_long_corr_fft)
 int launch_long_rcorr(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
-    if (!rcf_ready(p) || !p.corr_out) return ECHO_ERR_INVALID;
-    hipLaunchKernelGGL(long_rcorr_kernel, dim3(B * p.nb), dim3(kRcNT), rcf_smem(p), s, p);
+    if (!long_rcorr_fits(p) || !p.corr_out || (long)B * p.nb > 65535) return ECHO_ERR_INVALID;
+    hipLaunchKernelGGL(long_rcorr_kernel, dim3(p.rc_nblk, B * p.nb), dim3(kRcSplitNT), p.rc_smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
 }
 

@@ -602,7 +602,7 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             const int det = cfg->detector;
             if (rcf && std::atoi(rcf) != 0 && (det == ECHO_DET_MAD || det == ECHO_DET_TWOPEAK) &&
                 (det != ECHO_DET_MAD || h->lbase.L - h->lbase.half > h->lbase.min_delay) &&
-                plan_rcf(h->lbase, det == ECHO_DET_MAD ? h->lbase.half + h->lbase.min_delay : 0)) {
+                plan_rcf(h->lbase, det == ECHO_DET_MAD ? h->lbase.half + h->lbase.min_delay : 0, std::atoi(rcf) == 2)) {
                 std::vector<zd> wh, wk, rr, rg;
                 std::vector<int> pos;
                 rcf_tables(h->lbase, nb, cfg->chirps, wh, wk, rr, rg, pos);
@@ -1271,10 +1271,14 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             q.det_io = sc.pos; q.det_stride = q.corr_stride; q.det_off = 0; q.write_mutated = 0; q.res_out = sc.res;
             if (h->fuse_det && long_rcorr_det_fits(q)) {
                 rc = launch_long_rcorr_det(q, n, s);        // one real transform; the correlation stays in the workgroup
+            } else if (q.rc_nblk > 1 && long_rcorr_fits(q)) {
+                rc = launch_long_rcorr(q, n, s);            // blocks of lags, two workgroups per compute unit; detector apart
+                if (rc) return rc;
+                rc = launch_long_detect(q, n, s);
             } else if (h->fuse_det && long_corr_det_fits(q)) {
                 rc = launch_long_corr_det(q, n, s);         // the correlation stays in the workgroup that detects on it
             } else {
-                rc = long_rcorr_det_fits(q) ? launch_long_rcorr(q, n, s) : launch_long_corr(q, n, s);
+                rc = long_rcorr_fits(q) ? launch_long_rcorr(q, n, s) : launch_long_corr(q, n, s);
                 if (rc) return rc;
                 rc = launch_long_detect(q, n, s);
             }

@@ -65,6 +65,7 @@ int launch_long_corr_det(const LongParams& p, int B, hipStream_t s);
 // the same as one real transform per (frame, band) (rcf_phases.h), when LongParams::rc_use
 int rcf_kernel_prepare(const LongParams& p);
 bool long_rcorr_det_fits(const LongParams& p);
+bool long_rcorr_fits(const LongParams& p);
 int launch_long_rcorr_det(const LongParams& p, int B, hipStream_t s);
 int launch_long_rcorr(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);

@@ -97,8 +97,9 @@ struct LongParams {
     // of the histograms and scalars behind pos.
     // det_view 2: the single real transform of rcf_phases.h holds it: q - det_q0 = 2 i + w, component w of slot i + i/8.
     int det_view, det_q0, det_lds_off;
-    // matched filter as one real cyclic correlation (rcf_phases.h), chosen where every wanted lag fits one transform
-    int rc_use, rc_H, rc_npass, rc_k0, rc_smem;
+    // matched filter as real cyclic correlations (rcf_phases.h): block b of rc_nblk covers the rc_V lags from
+    // rc_k0 + b * rc_V on (one block where the detector runs in the same workgroup)
+    int rc_use, rc_H, rc_npass, rc_k0, rc_smem, rc_V, rc_nblk;
     int rc_radix[kRcMaxPass], rc_root_off[kRcMaxPass], rc_tw_off[kRcMaxPass];
     const cpx<double>* rc_wh;        // pass twiddles: per pass the runs exp(-2 pi i (i m) / S), m = 1..r-1, i < S / r
     const cpx<double>* rc_wk;        // [H/2 + 1] exp(-2 pi i k / 2H)

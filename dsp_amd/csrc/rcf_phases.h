@@ -30,26 +30,38 @@ namespace echo {
 constexpr int kRcNT = ECHO_RC_NT;                 // threads per workgroup
 
 // smallest H >= hmin that is a product of radices <= kGfftMaxBfly in at most kRcMaxPass passes; 0 if none below hmax
-inline bool rc_factor(int H, int* radix, int* npass) {
+inline bool rc_factor(int H, int* radix, int* npass, int max_radix = kGfftMaxBfly) {
     GfftPlan pl;
     if (!gfft_plan(pl, H, kRcNT, true) || pl.npass > kRcMaxPass) return false;
-    for (int i = 0; i < pl.npass; ++i) { if (!pl.bfly[i]) return false; radix[i] = pl.radix[i]; }
+    for (int i = 0; i < pl.npass; ++i) { if (!pl.bfly[i] || pl.radix[i] > max_radix) return false; radix[i] = pl.radix[i]; }
     *npass = pl.npass;
     return true;
 }
 
-// Plans the transform for LongParams p (N, M, L, half, k_begin set): fills p.rc_*; false when it does not apply.
-inline bool plan_rcf(LongParams& p, int k_begin) {
-    p.rc_use = 0; p.rc_H = 0; p.rc_npass = 0;
+constexpr int kRcSplitNT = 512;                   // threads of the block-wise kernel (two workgroups per compute unit)
+constexpr int kRcSplitLds = 80 * 1024;            // its LDS bound: half of a compute unit's
+constexpr int kRcSplitMaxR = 8;                   // its largest radix: four waves per SIMD leave 128 registers
+
+// Plans the transforms for LongParams p (N, M, L, half set) over the lags k_begin .. L-1: fills p.rc_*; false when it
+// does not apply.  split = false: ONE transform holds every lag (the detector can follow in the same workgroup).
+// split = true: blocks of V = 2H - (M - 1) lags, each a transform small enough for two workgroups to share a compute
+// unit's LDS; fewest blocks x passes x points wins.
+inline bool plan_rcf(LongParams& p, int k_begin, bool split = false) {
+    p.rc_use = 0; p.rc_H = 0; p.rc_npass = 0; p.rc_V = 0; p.rc_nblk = 0;
     const int nl = p.L - k_begin;
     if (nl < 1 || p.M < 512) return false;                   // short chirps keep the direct sum
-    const int hmin = (nl + p.M - 1 + 1) / 2;
-    // even H (the pair (k, H-k) then has its fixed point at H/2) within 4 % of the minimum; fewest passes x points wins
-    int best = 0, best_cost = 0, best_radix[kRcMaxPass], best_np = 0;
-    for (int H = hmin + (hmin & 1); H <= hmin + hmin / 25 + 16; H += 2) {
+    int best = 0, best_radix[kRcMaxPass], best_np = 0;
+    long best_cost = 0;
+    // even H: the pair (k, H-k) then has its fixed point at H/2
+    int hlo, hhi;
+    if (!split) { hlo = (nl + p.M - 1 + 1) / 2; hhi = hlo + hlo / 25 + 16; }      // within 4 % of the minimum
+    else { hlo = (p.M + 63) / 2; hhi = (kRcSplitLds / 16 - 1) * 8 / 9; }          // (H + H/8 + 1) * 16 <= the bound
+    for (int H = hlo + (hlo & 1); H <= hhi; H += 2) {
         int radix[kRcMaxPass], np = 0;
-        if (!rc_factor(H, radix, &np)) continue;
-        const int cost = np * H;
+        const int V = 2 * H - (p.M - 1);
+        // the block-wise kernel runs four waves per SIMD (128 registers): radices up to 8 fit without spilling
+        if (V < 1 || !rc_factor(H, radix, &np, split ? kRcSplitMaxR : kGfftMaxBfly)) continue;
+        const long cost = (long)((nl + V - 1) / V) * np * H;
         if (!best || cost < best_cost) {
             best = H; best_cost = cost; best_np = np;
             for (int i = 0; i < np; ++i) best_radix[i] = radix[i];
@@ -57,8 +69,11 @@ inline bool plan_rcf(LongParams& p, int k_begin) {
     }
     if (!best) return false;
     const long bytes = (long)(best + best / 8 + 1) * 16;
-    if (bytes + kDetExtra > 160 * 1024 || bytes + kCfTpExtra > 160 * 1024) return false;
+    if (!split && (bytes + kDetExtra > 160 * 1024 || bytes + kCfTpExtra > 160 * 1024)) return false;
+    if (split && bytes > kRcSplitLds) return false;
     p.rc_use = 1; p.rc_H = best; p.rc_npass = best_np; p.rc_k0 = k_begin;
+    p.rc_V = split ? 2 * best - (p.M - 1) : nl;
+    p.rc_nblk = (nl + p.rc_V - 1) / p.rc_V;
     int roff = 0;
     for (int i = 0; i < best_np; ++i) { p.rc_radix[i] = best_radix[i]; p.rc_root_off[i] = roff; roff += best_radix[i]; }
     p.rc_smem = (int)((bytes + 15) & ~15L);
@@ -135,10 +150,10 @@ inline void rcf_tables(LongParams& p, int nb, const double* chirps, std::vector<
 }
 
 // z[n] = u[2n] + i u[2n+1]
-ECHO_HD void ph_rc_load(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+ECHO_HD void ph_rc_load(int tid, int nt, int sub, int blk, const LongParams& p, unsigned char* smem) {
     zd* f = reinterpret_cast<zd*>(smem);
     const double* x = p.band_in + (size_t)blk * p.N;
-    const int o = p.rc_k0 - (p.M - 1);
+    const int o = p.rc_k0 + sub * p.rc_V - (p.M - 1);
     for (int n = tid; n < p.rc_H; n += nt) {
         const int a = o + 2 * n, b = a + 1;
         f[zpos(n)] = zmk((a >= 0 && a < p.N) ? x[a] : 0.0, (b >= 0 && b < p.N) ? x[b] : 0.0);
@@ -153,26 +168,30 @@ ECHO_HD void rc_pass(int tid, int nt, int S, const zd* roots, const zd* tw, cons
     const int q = S / R;
     for (int t = tid; t < p.rc_H / R; t += nt) {
         const int b = t / q, i = t - b * q, base = b * S + i;
-        zd v[R], w[R];
-#pragma unroll
-        for (int m = 1; m < R; ++m) w[m] = tw[(m - 1) * q + i];
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = f[zpos(base + j * q)];
+        zd v[R];
         if (INV) {
+            v[0] = f[zpos(base)];
 #pragma unroll
-            for (int m = 1; m < R; ++m) v[m] = zmulc(v[m], w[m]);
+            for (int m = 1; m < R; ++m) v[m] = zmulc(f[zpos(base + m * q)], tw[(m - 1) * q + i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = f[zpos(base + j * q)];
         }
         gfft_bfly<double, R>(v, roots, INV);
-        if (!INV) {
+        if (INV) {
 #pragma unroll
-            for (int m = 1; m < R; ++m) v[m] = zmul(v[m], w[m]);
+            for (int j = 0; j < R; ++j) f[zpos(base + j * q)] = v[j];
+        } else {
+            f[zpos(base)] = v[0];
+#pragma unroll
+            for (int m = 1; m < R; ++m) f[zpos(base + m * q)] = zmul(v[m], tw[(m - 1) * q + i]);
         }
-#pragma unroll
-        for (int j = 0; j < R; ++j) f[zpos(base + j * q)] = v[j];
     }
 }
 
-template <bool INV>
+// MAXR: the largest radix the kernel's plans hold (plan_rcf): larger butterflies are not compiled in, so they do not
+// count towards its register allocation
+template <bool INV, int MAXR = kGfftMaxBfly>
 ECHO_HD void ph_rc_pass(int tid, int nt, int ps, const LongParams& p, unsigned char* smem) {
     int S = p.rc_H;
     for (int i = 0; i < ps; ++i) S /= p.rc_radix[i];
@@ -186,8 +205,8 @@ ECHO_HD void ph_rc_pass(int tid, int nt, int ps, const LongParams& p, unsigned c
         case 6: rc_pass<6, INV>(tid, nt, S, roots, tw, p, smem); break;
         case 7: rc_pass<7, INV>(tid, nt, S, roots, tw, p, smem); break;
         case 8: rc_pass<8, INV>(tid, nt, S, roots, tw, p, smem); break;
-        case 9: rc_pass<9, INV>(tid, nt, S, roots, tw, p, smem); break;
-        case 10: rc_pass<10, INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 9: if (MAXR >= 9) rc_pass<(MAXR >= 9 ? 9 : 2), INV>(tid, nt, S, roots, tw, p, smem); break;
+        case 10: if (MAXR >= 10) rc_pass<(MAXR >= 10 ? 10 : 2), INV>(tid, nt, S, roots, tw, p, smem); break;
         default: break;
     }
 }
@@ -238,35 +257,37 @@ ECHO_HD void ph_rc_finish(int tid, int nt, const LongParams& p, unsigned char* s
     if (tid == 0) det_misc_init(det_misc(p, smem));
 }
 
-// stand-alone: lags [k_begin, L) to corr_out
-ECHO_HD void ph_rc_store(int tid, int nt, int blk, const LongParams& p, unsigned char* smem) {
+// stand-alone: the lags of block sub to corr_out
+ECHO_HD void ph_rc_store(int tid, int nt, int sub, int blk, const LongParams& p, unsigned char* smem) {
     const zd* f = reinterpret_cast<const zd*>(smem);
     double* out = p.corr_out + (size_t)blk * p.corr_stride - p.corr_k0;
-    const int nl = p.L - p.rc_k0;
+    const int k0 = p.rc_k0 + sub * p.rc_V;
+    const int nl = (p.L - k0) < p.rc_V ? (p.L - k0) : p.rc_V;
     for (int n = tid; 2 * n < nl; n += nt) {
         const zd v = f[zpos(n)];
-        out[p.rc_k0 + 2 * n] = v.x;
-        if (2 * n + 1 < nl) out[p.rc_k0 + 2 * n + 1] = v.y;
+        out[k0 + 2 * n] = v.x;
+        if (2 * n + 1 < nl) out[k0 + 2 * n + 1] = v.y;
     }
 }
 
-#define ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, blk, nt)                                     \
-    PHASE(ph_rc_load(tid, nt, blk, p, smem)) SYNC                                             \
-    for (int ps_ = 0; ps_ < (p).rc_npass; ++ps_) { PHASE(ph_rc_pass<false>(tid, nt, ps_, p, smem)) SYNC }   \
+#define ECHO_RC_TRANSFORM_R(PHASE, SYNC, p, smem, sub, blk, nt, MAXR)                        \
+    PHASE(ph_rc_load(tid, nt, sub, blk, p, smem)) SYNC                                        \
+    for (int ps_ = 0; ps_ < (p).rc_npass; ++ps_) { PHASE(ph_rc_pass<false, MAXR>(tid, nt, ps_, p, smem)) SYNC }   \
     PHASE(ph_rc_split(tid, nt, blk, p, smem)) SYNC                                            \
-    for (int ps_ = (p).rc_npass - 1; ps_ >= 0; --ps_) { PHASE(ph_rc_pass<true>(tid, nt, ps_, p, smem)) SYNC }
+    for (int ps_ = (p).rc_npass - 1; ps_ >= 0; --ps_) { PHASE(ph_rc_pass<true, MAXR>(tid, nt, ps_, p, smem)) SYNC }
+#define ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, sub, blk, nt) ECHO_RC_TRANSFORM_R(PHASE, SYNC, p, smem, sub, blk, nt, kGfftMaxBfly)
 
-#define ECHO_RC_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                       \
-    ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, blk, nt)                                          \
-    PHASE(ph_rc_store(tid, nt, blk, p, smem))
+#define ECHO_RC_SEQUENCE(PHASE, SYNC, p, smem, sub, blk, nt, MAXR)                            \
+    ECHO_RC_TRANSFORM_R(PHASE, SYNC, p, smem, sub, blk, nt, MAXR)                             \
+    PHASE(ph_rc_store(tid, nt, sub, blk, p, smem))
 
 #define ECHO_RC_DET_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                   \
-    ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, blk, nt)                                          \
+    ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, 0, blk, nt)                                       \
     PHASE(ph_rc_finish(tid, nt, p, smem)) SYNC                                                \
     ECHO_LDET_BODY(PHASE, SYNC, p, smem, blk, nt)
 
 #define ECHO_RC_TP_SEQUENCE(PHASE, SYNC, p, smem, blk, nt)                                    \
-    ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, blk, nt)                                          \
+    ECHO_RC_TRANSFORM(PHASE, SYNC, p, smem, 0, blk, nt)                                       \
     PHASE(ph_rc_finish(tid, nt, p, smem)) SYNC                                                \
     PHASE(if (tid < kLDetNT) ph_tp_scan_view(tid, kLDetNT, p, smem)) SYNC                     \
     PHASE(if (tid < kLDetNT) ph_tp_ref_fold(tid, kLDetNT, p, smem)) SYNC                      \

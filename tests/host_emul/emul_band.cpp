@@ -206,11 +206,12 @@ extern "C" int emul_long_corr_fft(int N, int M, int K, int nb, const double* chi
 #include "../../dsp_amd/csrc/rcf_phases.h"
 extern "C" int emul_long_rcorr(int N, int M, int K, int nb, const double* chirps, const double* band, int B, int k_begin,
                                int nt, double* corr_out, int detector, int min_delay, int noise_n, double gate,
-                               int* peak, double* snr, double* amp, int* valid) {
+                               int* peak, double* snr, double* amp, int* valid, int split) {
     LongParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_long(p, N, M, K, nb, min_delay, detector ? detector : 1)) return -2;
-    if (!plan_rcf(p, k_begin)) return -3;
+    if (!plan_rcf(p, k_begin, split != 0)) return -3;
+    if (detector && p.rc_nblk != 1) return -4;
     std::vector<zd> wh, wk, roots, g;
     std::vector<int> pos;
     rcf_tables(p, nb, chirps, wh, wk, roots, g, pos);
@@ -228,13 +229,18 @@ extern "C" int emul_long_rcorr(int N, int M, int K, int nb, const double* chirps
         std::memset(s, 0xff, smem.size());
         if (detector == 1) { ECHO_RC_DET_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
         else if (detector == 3) { ECHO_RC_TP_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
-        else { ECHO_RC_SEQUENCE(PHASE, SYNC, p, s, blk, nt); }
+        else {
+            for (int sub = 0; sub < p.rc_nblk; ++sub) {
+                std::memset(s, 0xff, smem.size());
+                ECHO_RC_SEQUENCE(PHASE, SYNC, p, s, sub, blk, nt, kGfftMaxBfly);
+            }
+        }
     }
 #undef PHASE
 #undef SYNC
     if (detector)
         for (size_t i = 0; i < res.size(); ++i) { peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude; valid[i] = res[i].pad; }
-    return p.rc_H;
+    return split ? p.rc_H * 16 + p.rc_nblk : p.rc_H;
 }
 
 // Generic mixed-radix FFT (dsp_amd/csrc/gfft.h), thread by thread.  in/out: n interleaved (re, im) doubles.

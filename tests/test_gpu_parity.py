@@ -419,21 +419,28 @@ def test_long_chain_detects_inside_the_matched_filter_kernel(which, monkeypatch)
     b, spec_b = apart.chain(rxs, n_streams=1, kalman=BatchedKalman(apart, 1), want_spectra=True)
     assert torch.equal(a, b) and torch.equal(spec_a, spec_b)
     assert _rec(a)["valid_mask"].any()
-    # both run the matched filter as one real transform per band; the two-sub-block transform it replaced
-    # (ECHO_RCF=0) computes the same correlation to rounding: same echoes, floats to 1e-9
-    monkeypatch.setenv("ECHO_RCF", "0")
-    blocks = _engine(cfg)
-    monkeypatch.delenv("ECHO_RCF")
-    c, spec_c = blocks.chain(rxs, n_streams=1, kalman=BatchedKalman(blocks, 1), want_spectra=True)
-    ra, rc = _rec(a), _rec(c)
-    assert torch.equal(spec_a, spec_c)
-    for k in ra.dtype.names:
-        x, y = np.asarray(ra[k]), np.asarray(rc[k])
-        if x.dtype.kind == "f":
-            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=k)
-        else:
-            assert np.array_equal(x, y), k
-    fused.close(); apart.close(); blocks.close()
+    # The matched filter as real transforms (rcf_phases.h; built, slower, opt-in): one transform with the detector in
+    # the same workgroup (ECHO_RCF=1) and blocks of lags small enough for two workgroups per compute unit, detector as
+    # a kernel of its own (ECHO_RCF=2).  They compute the same correlation
+    # to rounding: same echoes, floats to 1e-9.
+    ra = _rec(a)
+    for env in ({"ECHO_RCF": "1"}, {"ECHO_RCF": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = _engine(cfg)
+        for k in env:
+            monkeypatch.delenv(k)
+        c, spec_c = e.chain(rxs, n_streams=1, kalman=BatchedKalman(e, 1), want_spectra=True)
+        rc = _rec(c)
+        assert torch.equal(spec_a, spec_c)
+        for k in ra.dtype.names:
+            x, y = np.asarray(ra[k]), np.asarray(rc[k])
+            if x.dtype.kind == "f":
+                np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=f"{env} {k}")
+            else:
+                assert np.array_equal(x, y), (env, k)
+        e.close()
+    fused.close(); apart.close()
 
 
 @pytest.mark.parametrize("n_rx", [8820, 8822])

@@ -248,7 +248,7 @@ def test_emulated_real_transform_matched_filter(emul):
     very correlation values (indices exact, SNR to 1e-12)."""
     from oracle import echo_oracle as O
     P, I, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
-    emul.emul_long_rcorr.argtypes = [I, I, I, I, P, P, I, I, I, P, I, I, I, D, P, P, P, P]
+    emul.emul_long_rcorr.argtypes = [I, I, I, I, P, P, I, I, I, P, I, I, I, D, P, P, P, P, I]
     rng = np.random.default_rng(11)
     fs = 48000
     # (N, M, detector, min_delay): airSonar.py's sizes (MAD detector, lags from half + min_delay), 666.py's (two-peak,
@@ -272,16 +272,26 @@ def test_emulated_real_transform_matched_filter(emul):
         corr = np.full((B, nb, L), np.nan)
         peak = np.zeros((B, nb), np.int32); snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); valid = np.zeros((B, nb), np.int32)
         H = emul.emul_long_rcorr(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, nt, _ptr(corr), 0, min_delay, 0,
-                                 6.0, None, None, None, None)
+                                 6.0, None, None, None, None, 0)
         assert H > 0 and 2 * H >= L - k_begin + M - 1
         for b in range(B):
             for j in range(nb):
                 ref = np.correlate(band[b, j], chirps[j], "full")
                 assert np.isnan(corr[b, j, :k_begin]).all()
                 assert np.abs(corr[b, j, k_begin:] - ref[k_begin:]).max() <= 4e-15 * max(np.abs(ref).max(), 1e-300)
+        # the same lags in blocks, each a transform that leaves half of a compute unit's LDS to another workgroup
+        if M >= 512 and N >= 7200:
+            blocks = np.full((B, nb, L), np.nan)
+            r = emul.emul_long_rcorr(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, 512, _ptr(blocks), 0, min_delay,
+                                     0, 6.0, None, None, None, None, 1)
+            Hs, nblk = r // 16, r % 16
+            assert r > 0 and nblk >= 2 and (Hs + Hs // 8 + 1) * 16 <= 80 * 1024 and nblk * (2 * Hs - (M - 1)) >= L - k_begin
+            assert np.isnan(blocks[:, :, :k_begin]).all()
+            scale = np.abs(corr[:, :, k_begin:]).max(axis=-1, keepdims=True)
+            assert (np.abs(blocks[:, :, k_begin:] - corr[:, :, k_begin:]) <= 4e-15 * np.maximum(scale, 1e-300)).all()
         noise_n = int((L - half) * 0.2)
         assert emul.emul_long_rcorr(N, M, 101, nb, _ptr(chirps), _ptr(band), B, k_begin, nt, None, det, min_delay,
-                                    noise_n, 6.0, _ptr(peak), _ptr(snr), _ptr(amp), _ptr(valid)) == H
+                                    noise_n, 6.0, _ptr(peak), _ptr(snr), _ptr(amp), _ptr(valid), 0) == H
         for b in range(B):
             for j in range(nb):
                 c = np.where(np.isnan(corr[b, j]), 0.0, corr[b, j])
