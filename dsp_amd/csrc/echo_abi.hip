@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -121,6 +122,7 @@ struct EchoHandle {
     int iir_side = 0, iir_cus = 0, iir_side_min = 2048;
     int iir_side_full = 0, iir_cus_full = 0;   // the same for echo_chain_full calls of short-frame handles
     long long side_passes = 0;             // passes whose IIR ran on that stream (echo_confined_iir_passes)
+    bool counted = false;                  // included in the count of live handles (release_shared_streams)
     // profiling: a ring of event quads, one per profiled echo_chain call (first pass of the call)
     bool prof = false;
     std::vector<hipEvent_t> ev;            // 6 events per slot: start, after IIR, after band, after spectrum, end, after the pair kernel
@@ -148,7 +150,28 @@ namespace {
 std::mutex g_side_mu;
 struct SideStream { int ncu; hipStream_t st; };
 std::vector<SideStream> g_side_streams[kMaxDevices];
+struct InFlight { const void* who; hipEvent_t done; bool set; };
+constexpr int kInFlight = 4;
+InFlight g_inflight[kMaxDevices][kInFlight];
+int g_inflight_next[kMaxDevices];
+std::atomic<int> g_live_handles{0};
+
+// The shared streams and events live as long as a handle does: the last echo_destroy releases them, and so does the
+// end of the process for handles never destroyed (a compute-unit-masked stream still alive when the profiler's
+// finaliser ran crashed rocprofv3 at exit).
+void release_shared_streams() {
+    std::lock_guard<std::mutex> guard(g_side_mu);
+    for (int d = 0; d < kMaxDevices; ++d) {
+        for (SideStream& e : g_side_streams[d]) { (void)hipStreamSynchronize(e.st); (void)hipStreamDestroy(e.st); }
+        g_side_streams[d].clear();
+        for (InFlight& e : g_inflight[d]) { if (e.done) (void)hipEventDestroy(e.done); e = InFlight{nullptr, nullptr, false}; }
+        g_inflight_next[d] = 0;
+    }
+}
+
 hipStream_t side_stream(int device, int ncu) {
+    static std::once_flag at_exit;
+    std::call_once(at_exit, [] { std::atexit(release_shared_streams); });
     std::lock_guard<std::mutex> guard(g_side_mu);
     for (const SideStream& e : g_side_streams[device]) if (e.ncu == ncu) return e.st;
     hipStream_t st = nullptr;
@@ -163,11 +186,6 @@ hipStream_t side_stream(int device, int ncu) {
 
 // Batches in flight: per device, an event at the end of the latest chain pass of each of the last few handles.  The
 // events belong to this table, not to the handles, which come and go.  Guarded by g_side_mu.
-struct InFlight { const void* who; hipEvent_t done; bool set; };
-constexpr int kInFlight = 4;
-InFlight g_inflight[kMaxDevices][kInFlight];
-int g_inflight_next[kMaxDevices];
-
 bool others_in_flight(const EchoHandle* h) {
     std::lock_guard<std::mutex> guard(g_side_mu);
     for (const InFlight& e : g_inflight[h->device])
@@ -650,6 +668,8 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     h->lbase.taps_rev = h->d_taps_rev; h->lbase.chirp = h->d_chirp;
     // the cfg table pointers are host pointers owned by the caller; do not keep them
     h->cfg.b = h->cfg.a = h->cfg.zi = h->cfg.taps = h->cfg.chirps = nullptr;
+    h->counted = true;
+    g_live_handles.fetch_add(1);
     *out = h;
     return ECHO_OK;
 }
@@ -690,7 +710,9 @@ void echo_destroy(EchoHandle* h) {
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     (void)hipFree(h->pf_y[0]); (void)hipFree(h->pf_y[1]); (void)hipFree(h->pf_fwd);
+    const bool last = h->counted && g_live_handles.fetch_sub(1) == 1;
     delete h;
+    if (last) release_shared_streams();
 }
 
 int echo_reserve(EchoHandle* h, int max_frames) {
@@ -1402,7 +1424,7 @@ static EchoHandle* clone_for_lane(const EchoHandle* h) {
     for (int i = 0; i < 3; ++i) { c->lane_stream[i] = nullptr; c->lane_join[i] = nullptr; c->lane_kal[i] = nullptr; }
     c->lane_fork = nullptr; c->lanes_ready = false;
     c->last_stream = nullptr; c->last_stream_set = false; c->xs_event = nullptr;
-    c->side_fork = nullptr; c->side_join = nullptr; c->side_passes = 0;
+    c->side_fork = nullptr; c->side_join = nullptr; c->side_passes = 0; c->counted = false;
     return c;
 }
 

@@ -18,9 +18,16 @@ kal = BatchedKalman(eng, S)
 recs = [torch.empty((B, 64), dtype=torch.uint8, device="cuda") for _ in range(3)]
 specs = [torch.empty((B, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device="cuda") for _ in range(3)]
 
+STAGGER_US = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+
+
 def run(n, events):
     evs = []
     for i in range(n):
+        if STAGGER_US and events and 0 < i < 3:
+            t = time.perf_counter()
+            while (time.perf_counter() - t) * 1e6 < STAGGER_US:
+                pass
         evs.append(lanes.submit(rx, n_streams=S, kalman=kal, out=recs[i % 3], spec_out=specs[i % 3], inputs_ready=True,
                                 want_event=events))
     return evs
