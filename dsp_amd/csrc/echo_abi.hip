@@ -159,8 +159,9 @@ std::atomic<int> g_live_handles{0};
 // The shared streams and events live as long as a handle does: the last echo_destroy releases them, and so does the
 // end of the process for handles never destroyed (a compute-unit-masked stream still alive when the profiler's
 // finaliser ran crashed rocprofv3 at exit).
-void release_shared_streams() {
+void release_shared_streams_if(bool at_exit) {
     std::lock_guard<std::mutex> guard(g_side_mu);
+    if (!at_exit && g_live_handles.load() != 0) return;      // a handle was created in the meantime
     for (int d = 0; d < kMaxDevices; ++d) {
         for (SideStream& e : g_side_streams[d]) { (void)hipStreamSynchronize(e.st); (void)hipStreamDestroy(e.st); }
         g_side_streams[d].clear();
@@ -169,9 +170,11 @@ void release_shared_streams() {
     }
 }
 
+void release_shared_streams() { release_shared_streams_if(false); }
+
 hipStream_t side_stream(int device, int ncu) {
     static std::once_flag at_exit;
-    std::call_once(at_exit, [] { std::atexit(release_shared_streams); });
+    std::call_once(at_exit, [] { std::atexit([] { release_shared_streams_if(true); }); });
     std::lock_guard<std::mutex> guard(g_side_mu);
     for (const SideStream& e : g_side_streams[device]) if (e.ncu == ncu) return e.st;
     hipStream_t st = nullptr;
@@ -1257,6 +1260,12 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             // wait at the head of the shared stream would hold up the other handles' IIRs queued behind it
             use_side = plain && (side_mode == 1 || (n == B && n >= h->iir_side_min && others_in_flight(h)));
         }
+        hipStream_t side = nullptr;
+        if (use_side && !(side = side_stream(h->device, side_cus))) {
+            // no such stream on this device (a partition mode without compute-unit masks, say): the IIR stays in line
+            h->iir_side = h->iir_side_full = 0;
+            use_side = track = false;
+        }
         if (pre) {
             if (hipStreamWaitEvent(s, h->pf_ready[pre_slot], 0) != hipSuccess) return ECHO_ERR_HIP;
             y_in = h->pf_y[pre_slot];
@@ -1266,8 +1275,6 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 h->pf_valid = false;
             }
         } else if (use_side) {
-            hipStream_t side = side_stream(h->device, side_cus);
-            if (!side) return ECHO_ERR_HIP;
             if (!h->side_fork && (hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming) != hipSuccess ||
                                   hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming) != hipSuccess)) return ECHO_ERR_HIP;
             ++h->side_passes;
