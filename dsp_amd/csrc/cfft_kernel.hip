@@ -6,6 +6,7 @@
 #include "echo_internal.h"
 #include "cfft_phases.h"
 #include "rcf_phases.h"
+#include "ospec_phases.h"
 
 namespace echo {
 
@@ -129,6 +130,32 @@ int launch_long_rcorr(const LongParams& p, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (!long_rcorr_fits(p) || !p.corr_out || (long)B * p.nb > 65535) return ECHO_ERR_INVALID;
     hipLaunchKernelGGL(long_rcorr_kernel, dim3(p.rc_nblk, B * p.nb), dim3(kRcSplitNT), p.rc_smem, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
+}
+
+// Spectrum of an odd-length long frame, chirp-z convolution with the transform in place (ospec_phases.h)
+__global__ __launch_bounds__(kOsNT) void long_spec_odd_ip_kernel(LongParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+#define ECHO_PHASE(...) { __VA_ARGS__; }
+#define ECHO_SYNC __syncthreads();
+    ECHO_OSPEC_SEQUENCE(ECHO_PHASE, ECHO_SYNC, p, smem, blk, kOsNT);
+#undef ECHO_PHASE
+#undef ECHO_SYNC
+}
+
+int ospec_kernel_prepare(const LongParams& p) {
+    if (!p.os_use) return ECHO_OK;
+    if (p.os_smem > 160 * 1024) return ECHO_ERR_INVALID;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(long_spec_odd_ip_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, p.os_smem) == hipSuccess ? ECHO_OK : ECHO_ERR_HIP;
+}
+
+int launch_long_spec_odd_ip(const LongParams& p, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (!p.os_use || !p.os_tw || !p.os_roots || !p.os_bhat || !p.sbw || !p.spec_in || !p.spec_out ||
+        p.os_m < p.N + p.nbins - 1) return ECHO_ERR_INVALID;
+    hipLaunchKernelGGL(long_spec_odd_ip_kernel, dim3(B * p.nb), dim3(kOsNT), p.os_smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : ECHO_ERR_HIP;
 }
 

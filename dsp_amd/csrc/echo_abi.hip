@@ -78,6 +78,7 @@ struct EchoHandle {
     cpx<double> *d_cfg = nullptr, *d_cfw2 = nullptr, *d_cftw = nullptr;   // long path: FFT matched filter tables
     cpx<double> *d_rcwh = nullptr, *d_rcwk = nullptr, *d_rcroots = nullptr, *d_rcg = nullptr;   // the same as one real transform
     int* d_rcpos = nullptr;
+    cpx<float> *d_ostw = nullptr, *d_osroots = nullptr, *d_osbhat = nullptr, *d_osbw = nullptr;   // odd-length spectrum in place
     // cross-batch pipelining: the IIR of the next batch on a stream of the handle's own (echo_chain_prefetch)
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_ready[2] = {nullptr, nullptr}, pf_consumed[2] = {nullptr, nullptr}, pf_t0 = nullptr, pf_t1 = nullptr;
@@ -430,9 +431,10 @@ bool detector_supported(const EchoHandle* h) {
 }
 
 // spectra of long frames: the mixed-radix / chirp-z kernel where the frame length has a plan, direct sums otherwise
-bool long_spec_available(const EchoHandle* h) { return h->lbase.has_spec || h->d_dftw; }
+bool long_spec_available(const EchoHandle* h) { return h->lbase.has_spec || h->lbase.os_use || h->d_dftw; }
 int run_long_spec(const EchoHandle* h, const LongParams& q, int rows_frames, hipStream_t s) {
     if (h->lbase.has_spec) return launch_long_spec(q, rows_frames, s);
+    if (h->lbase.os_use) return launch_long_spec_odd_ip(q, rows_frames, s);
     if (!h->d_dftw) return ECHO_ERR_UNSUPPORTED;
     const int rc = launch_dft_rows(q.spec_in, h->d_dftw, q.spec_out, q.spec_db, rows_frames * q.nb, q.N, s);
     return rc == 0 ? ECHO_OK : ECHO_ERR_HIP;
@@ -594,7 +596,18 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
                 h->lbase.sbw = h->d_lbw; h->lbase.sbhat = h->d_lbhat;
             }
         }
-        if (!h->lbase.has_spec && cfg->n_rx <= kSpecDftMax) {
+        if (!h->lbase.has_spec && plan_ospec(h->lbase)) {
+            // an odd frame length beyond the two-buffer chirp-z kernel: the same convolution with the transform in place
+            std::vector<zf> tw, rr, bw, bh;
+            ospec_tables(h->lbase, tw, rr, bw, bh);
+            up(dev_upload(&h->d_ostw, tw.data(), tw.size()));
+            up(dev_upload(&h->d_osroots, rr.data(), rr.size()));
+            up(dev_upload(&h->d_osbw, bw.data(), bw.size()));
+            up(dev_upload(&h->d_osbhat, bh.data(), bh.size()));
+            h->lbase.os_tw = h->d_ostw; h->lbase.os_roots = h->d_osroots; h->lbase.os_bhat = h->d_osbhat; h->lbase.sbw = h->d_osbw;
+            if (rc == ECHO_OK) rc = ospec_kernel_prepare(h->lbase);
+        }
+        if (!h->lbase.has_spec && !h->lbase.os_use && cfg->n_rx <= kSpecDftMax) {
             // a frame length none of the FFT kernels takes (e.g. an odd N beyond one workgroup's LDS): spectra as direct
             // float64 sums, O(N^2) per frame and band
             std::vector<double2> w((size_t)cfg->n_rx);
@@ -698,7 +711,8 @@ void echo_destroy(EchoHandle* h) {
     void* tabs[] = {h->d_b, h->d_a, h->d_zi, h->d_taps_rev, h->d_chirp, h->d_bw, h->d_bhat, h->d_tw, h->d_post,
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw,
-                    h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos};
+                    h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos,
+                    h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {

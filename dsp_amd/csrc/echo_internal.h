@@ -70,6 +70,9 @@ int launch_long_rcorr_det(const LongParams& p, int B, hipStream_t s);
 int launch_long_rcorr(const LongParams& p, int B, hipStream_t s);
 int launch_long_detect(const LongParams& p, int B, hipStream_t s);
 int launch_long_spec(const LongParams& p, int B, hipStream_t s);
+// odd frame lengths beyond launch_long_spec's two LDS buffers (ospec_phases.h), when LongParams::os_use
+int ospec_kernel_prepare(const LongParams& p);
+int launch_long_spec_odd_ip(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);
 int launch_corr_env(const EnvParams& p, int B, hipStream_t s);
 int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,

@@ -119,6 +119,12 @@ struct LongParams {
     int spec_odd, sb_m;              // sb_m >= N + nbins - 1, a product of 2, 3, 5, 7 (splan is then the plan of sb_m)
     const cpx<float>* sbw;           // global: N chirp factors w[n] = exp(-i pi n^2 / N)
     const cpx<float>* sbhat;         // global: sb_m, DFT of the chirp filter conj(w) / sb_m
+    // odd N beyond two LDS buffers: the same convolution with the transform in place (ospec_phases.h)
+    int os_use, os_m, os_npass, os_smem;
+    int os_radix[kRcMaxPass], os_root_off[kRcMaxPass], os_tw_off[kRcMaxPass];
+    const cpx<float>* os_tw;         // pass twiddles
+    const cpx<float>* os_roots;      // per pass the r roots of unity
+    const cpx<float>* os_bhat;       // [os_m] DFT of the chirp filter in pass order, / os_m
     int det_stages, det_passes;      // development aids: run only the first stages / passes of the detector (0 = all)
     int noise_n;                     // two-peak detector: length of the noise region of pos
     double snr_gate;

@@ -11,6 +11,7 @@
 #include "band_phases.h"
 #include "cfft_phases.h"
 #include "rcf_phases.h"
+#include "ospec_phases.h"
 #include "fft9_phases.h"
 
 namespace echo {

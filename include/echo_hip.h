@@ -110,10 +110,10 @@ typedef struct EchoHandle EchoHandle;
 
 /* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
  * (airSonar_optimized.py:598-619).  Uses the current HIP device.
- * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution where that fits a
- * workgroup's LDS (odd n_rx up to about 6600); frame lengths no FFT kernel holds (longer odd ones, even ones whose half
- * has a prime factor the mixed-radix passes do not take) get their spectra as direct float64 sums, O(n_rx^2) per frame
- * and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
+ * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution in a workgroup's LDS
+ * (odd n_rx up to about 12,100: in two buffers up to about 6600, with the transform in place beyond); frame lengths no
+ * FFT kernel holds (longer odd ones, even ones whose half has a prime factor the mixed-radix passes do not take) get
+ * their spectra as direct float64 sums, O(n_rx^2) per frame and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
  * echo_chain_full takes every even correlation length of the single-workgroup kernels: where half of it has a large prime
@@ -149,7 +149,7 @@ int echo_spectrum_rows(EchoHandle* h, const double* x, float* spec, int db, int 
 /* gpu_spectrum / mag2db(np.fft.rfft(x)) for signals of ANY length n (airSonar_optimized.py:332-343, :710; np.fft.rfft
  * has no length restriction): x[rows][n] float64 -> spec[rows][n/2+1] float32, |X| or its dB as echo_spectrum.  No
  * handle: a length the FFT kernels hold (even n up to about 19,000 whose half has small prime factors or fits the
- * Bluestein kernels, odd n up to about 6600) gets a plan of its own on first use, kept per (device, n) until the process
+ * Bluestein kernels, odd n up to about 12,100) gets a plan of its own on first use, kept per (device, n) until the process
  * ends; every other length up to 2^18 runs as direct float64 sums (O(n^2) per row, exact to rounding).  Thread-safe.
  * ECHO_ERR_UNSUPPORTED: n beyond 2^18 without an FFT plan. */
 int echo_spectrum_any(const double* x, float* spec, int db, int rows, int n, void* stream);

@@ -400,6 +400,31 @@ extern "C" int emul_long_spec(int N, int M, int K, int nb, const double* band, i
     return 0;
 }
 
+// Spectrum of an odd-length long frame with the transform in place (ospec_phases.h).  Returns the cyclic length, or
+// -2 when the frame length takes another kernel (even, or short enough for two buffers) or none.
+#include "../../dsp_amd/csrc/ospec_phases.h"
+extern "C" int emul_ospec(int N, int M, int K, int nb, const double* band, int B, int db, float* spec_out) {
+    LongParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_long(p, N, M, K, nb, 0, 1) || !plan_ospec(p)) return -2;
+    std::vector<zf> tw, roots, bw, bhat;
+    ospec_tables(p, tw, roots, bw, bhat);
+    p.os_tw = tw.data(); p.os_roots = roots.data(); p.os_bhat = bhat.data(); p.sbw = bw.data();
+    p.spec_db = db; p.spec_in = band; p.spec_out = spec_out;
+    std::vector<unsigned char> smem(p.os_smem);
+    unsigned char* s = smem.data();
+    const int nt = kOsNT;
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        ECHO_OSPEC_SEQUENCE(PHASE, SYNC, p, s, blk, nt);
+    }
+#undef SYNC
+#undef PHASE
+    return p.os_m;
+}
+
 // 4608-point variant of the spectrum kernel (dsp_amd/csrc/fft9_phases.h).
 extern "C" int emul_spec9(int N, int M, int K, int nb, const double* taps, const double* chirps, const double* band,
                           int B, float* spec_out) {

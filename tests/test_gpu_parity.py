@@ -222,8 +222,8 @@ def test_chain_with_odd_frame_length():
     """An odd number of samples per frame (N = 4795; np.fft.rfft has no length restriction, airSonar_optimized.py:710):
     no half-length packing exists, the spectrum is a chirp-z convolution through the mixed-radix FFT; everything else of
     the chain runs on the tiled kernels.  Against the oracle, spectra included, through the chain and through the
-    standalone entry point.  An odd frame too long for that convolution to fit a workgroup's LDS (N = 8821) gets its
-    spectra as direct float64 sums."""
+    standalone entry point.  An odd frame too long for that convolution's two LDS buffers (N = 8821) takes the same
+    convolution with the transform in place in one buffer (ospec_phases.h)."""
     from dsp_amd._lib import EchoError
     from dataclasses import replace
     cfg = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=0.0999)
@@ -248,7 +248,7 @@ def test_chain_with_odd_frame_length():
     exp = O.chain(rx, e.tables.chirps_f32, e.tables.filters, cfg, mode="named", keep=("spec_db",))
     rec, _ = e.chain(rx, want_spectra=False)
     check_records(_rec(rec), exp)
-    rec2, spec = e.chain(rx, want_spectra=True)                # no FFT kernel holds this length: direct float64 sums
+    rec2, spec = e.chain(rx, want_spectra=True)                # chirp-z convolution of length 13440, in place
     assert torch.equal(rec, rec2) and spec.shape == (8, cfg.n_bands, 4411)
     check_spectra(spec.cpu().numpy(), exp["spec_db"])
     e.close()

@@ -151,6 +151,29 @@ def test_emulated_odd_length_spectrum(emul):
     assert (np.abs(lin - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 1e-5
 
 
+def test_emulated_odd_length_spectrum_in_place(emul):
+    """Odd frame lengths beyond the two-buffer chirp-z kernel (N > ~6700): the same convolution with the transform in
+    place in one LDS buffer (ospec_phases.h), thread by thread, against np.fft.rfft; lengths with other radix sets, the
+    largest one near the LDS bound."""
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_ospec.argtypes = [I, I, I, I, P, I, I, P]
+    rng = np.random.default_rng(9)
+    for N in (8821, 7001, 12001):
+        nb = 2
+        bs = rng.standard_normal((1, nb, N)) * np.hanning(N)
+        bs[0, 1] *= 1e-3
+        bs = np.ascontiguousarray(bs)
+        spec = np.zeros((1, nb, N // 2 + 1), np.float32)
+        m = emul.emul_ospec(N, 275, 61, nb, _ptr(bs), 1, 0, _ptr(spec))
+        assert m >= N + N // 2 and (m + m // 8 + 1) * 8 <= 160 * 1024, (N, m)
+        ref = np.abs(np.fft.rfft(bs, axis=-1))
+        assert (np.abs(spec - ref).max(axis=-1) / ref.max(axis=-1)).max() <= 2e-5, N
+    # even lengths and short odd ones keep their own kernels
+    bs = np.zeros((1, 1, 4795)); spec = np.zeros((1, 1, 2398), np.float32)
+    assert emul.emul_ospec(4795, 275, 61, 1, _ptr(bs), 1, 0, _ptr(spec)) == -2
+    assert emul.emul_ospec(8820, 275, 61, 1, _ptr(bs), 1, 0, _ptr(spec)) == -2
+
+
 def test_emulated_long_frame_detectors_against_oracle(emul):
     """The four detectors of the tiled long-frame path, thread by thread, on synthetic correlations (noise, one or two
     peaks, silence, ties, a peak inside the blind zone) against the oracle's first_strong_peak functions: indices
