@@ -1,5 +1,6 @@
-// Spectrum of a long frame of ODD length whose chirp-z convolution does not fit two LDS buffers (long_phases.h,
-// long_spec_odd_kernel: N up to ~6700): the same convolution with the transform IN PLACE in one buffer, float32.
+// Spectrum of a long frame whose length no other kernel holds -- ODD lengths whose chirp-z convolution does not fit two
+// LDS buffers (long_phases.h, long_spec_odd_kernel: N up to ~6700), even lengths whose half has a large prime factor --
+// as that convolution with the transform IN PLACE in one buffer, float32.
 //   X[k] = w[k] sum_n (x[n] w[n]) conj(w)[k - n],  w[n] = exp(-i pi n^2 / N),  0 <= k <= N/2  (np.fft.rfft of any length,
 //   airSonar_optimized.py:710; N is odd for about half of all listening-window settings)
 // as a cyclic convolution of length m >= N + N/2 (products of radices <= 10):
@@ -23,10 +24,12 @@ ECHO_HD zf zfmk(float x, float y) { zf r; r.x = x; r.y = y; return r; }
 ECHO_HD zf zfmul(zf a, zf b) { return zfmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 ECHO_HD zf zfmulc(zf a, zf b) { return zfmk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 
-// Plans the convolution for an odd N without a two-buffer plan: fills p.os_*; false when none fits.
+// Plans the convolution for a frame length no other spectrum kernel holds (odd N beyond two LDS buffers; even N whose
+// half has a prime factor the mixed-radix passes do not take -- the chirp-z form needs nothing of N): fills p.os_*;
+// false when none fits.
 inline bool plan_ospec(LongParams& p) {
     p.os_use = 0; p.os_m = 0; p.os_npass = 0; p.os_smem = 0;
-    if (p.N % 2 == 0 || p.has_spec) return false;
+    if (p.has_spec) return false;
     int best = 0, best_radix[kRcMaxPass], best_np = 0;
     long best_cost = 0;
     const int lo = p.N + p.nbins - 1;

@@ -111,9 +111,9 @@ typedef struct EchoHandle EchoHandle;
 /* Set-up: replaces SonarWorker.__init__'s design_filters/generate_chirps/`cp.asarray(taps)` preload
  * (airSonar_optimized.py:598-619).  Uses the current HIP device.
  * Sizes: frames with an odd n_rx run on the tiled kernels, their spectra as a chirp-z convolution in a workgroup's LDS
- * (odd n_rx up to about 12,100: in two buffers up to about 6600, with the transform in place beyond); frame lengths no
- * FFT kernel holds (longer odd ones, even ones whose half has a prime factor the mixed-radix passes do not take) get
- * their spectra as direct float64 sums, O(n_rx^2) per frame and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
+ * (in two buffers up to n_rx of about 6600, with the transform in place up to about 12,100; long even frames whose half
+ * has a prime factor the mixed-radix passes do not take go the same way); longer frames without an FFT plan get their
+ * spectra as direct float64 sums, O(n_rx^2) per frame and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
  * echo_chain_full takes every even correlation length of the single-workgroup kernels: where half of it has a large prime

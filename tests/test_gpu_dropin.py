@@ -363,7 +363,7 @@ def test_spectrum_of_any_length(engines):
     from dsp_amd import dropin as D
     D.use_engine(engines["default"])
     rng = np.random.default_rng(3)
-    for n in (4282, 4800, 8820, 4795, 1000, 64, 4283, 9973, 19997, 8821, 63, 7, 2, 1, 6000, 12000):
+    for n in (4282, 4800, 8820, 4795, 1000, 64, 4283, 9973, 19997, 8821, 8818, 63, 7, 2, 1, 6000, 12000):
         t = np.arange(n)
         x = rng.standard_normal(n) * 0.1 + np.sin(2 * np.pi * 0.11 * t) + 0.3 * np.cos(2 * np.pi * 0.31 * t)
         ref = np.abs(np.fft.rfft(x))

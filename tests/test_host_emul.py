@@ -154,11 +154,11 @@ def test_emulated_odd_length_spectrum(emul):
 def test_emulated_odd_length_spectrum_in_place(emul):
     """Odd frame lengths beyond the two-buffer chirp-z kernel (N > ~6700): the same convolution with the transform in
     place in one LDS buffer (ospec_phases.h), thread by thread, against np.fft.rfft; lengths with other radix sets, the
-    largest one near the LDS bound."""
+    largest one near the LDS bound, and an even length whose half is prime."""
     P, I = ctypes.c_void_p, ctypes.c_int
     emul.emul_ospec.argtypes = [I, I, I, I, P, I, I, P]
     rng = np.random.default_rng(9)
-    for N in (8821, 7001, 12001):
+    for N in (8821, 7001, 12001, 8818):                      # 8818 = 2 * 4409: even, its half a prime
         nb = 2
         bs = rng.standard_normal((1, nb, N)) * np.hanning(N)
         bs[0, 1] *= 1e-3
