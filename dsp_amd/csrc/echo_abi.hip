@@ -68,6 +68,8 @@ struct EchoHandle {
     bool has_env = false;                  // envelope branch available (even correlation length with small prime factors)
     EnvParams ebase;
     cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr, *d_ebsw = nullptr, *d_ebsb = nullptr;
+    cpx<double> *d_eltw = nullptr, *d_elwk = nullptr; double* d_elgam = nullptr;   // Hilbert transform as one real convolution
+    int env_lin = 1;                       // ECHO_ENV_LIN=0: the envelope branch keeps the half-length transforms
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
@@ -107,7 +109,7 @@ struct EchoHandle {
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
     // envelope plans for signals other than the correlation (echo_envelope_rows), made on first use
-    struct EnvPlan { int L, smooth; EnvParams p; cpx<double> *roots, *wn, *wl, *bsw, *bsb; };
+    struct EnvPlan { int L, smooth; EnvParams p; cpx<double> *roots, *wn, *wl, *bsw, *bsb, *ltw, *lwk; double* lgam; };
     std::vector<EnvPlan> env_plans;
     EnvRes* d_env_rows = nullptr; size_t env_rows_cap = 0;
     Scratch sc;                            // allocated by ensure_scratch
@@ -654,13 +656,23 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
     }
     if (rc == ECHO_OK && nc > 1 && iir_kernel_prepare() != 0) rc = ECHO_ERR_HIP;
     std::memset(&h->ebase, 0, sizeof(h->ebase));
+    if (const char* el = std::getenv("ECHO_ENV_LIN")) h->env_lin = std::atoi(el);
     if (rc == ECHO_OK && !h->long_path &&
-        plan_env(h->ebase, cfg->n_rx + cfg->n_chirp - 1, nb, cfg->min_delay, 5)) {
+        plan_env(h->ebase, cfg->n_rx + cfg->n_chirp - 1, nb, cfg->min_delay, 5, h->env_lin != 0)) {
         std::vector<cpx<double>> er, ewn, ewl;
+        if (h->ebase.lin) {
+            std::vector<double> gam;
+            envlin_tables(h->ebase.L, er, ewn, gam);
+            up(dev_upload(&h->d_eltw, er.data(), er.size()));
+            up(dev_upload(&h->d_elwk, ewn.data(), ewn.size()));
+            up(dev_upload(&h->d_elgam, gam.data(), gam.size()));
+            h->ebase.lin_tw = h->d_eltw; h->ebase.lin_wk = h->d_elwk; h->ebase.lin_gam = h->d_elgam;
+        } else {
         env_tables(h->ebase, er, ewn, ewl);
         up(dev_upload(&h->d_eroots, er.data(), er.size()));
         up(dev_upload(&h->d_ewn, ewn.data(), ewn.size()));
         up(dev_upload(&h->d_ewl, ewl.data(), ewl.size()));
+        }
         if (h->ebase.bs_m) {
             // half the correlation length has a prime factor beyond the mixed-radix passes (e.g. L = 4562 = 2 * 2281):
             // the Hilbert transform's half-length FFTs run as Bluestein convolutions, as in echo_envelope_rows
@@ -712,11 +724,12 @@ void echo_destroy(EchoHandle* h) {
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw,
                     h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos,
-                    h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw};
+                    h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw, h->d_eltw, h->d_elwk, h->d_elgam};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
         (void)hipFree(pl.roots); (void)hipFree(pl.wn); (void)hipFree(pl.wl); (void)hipFree(pl.bsw); (void)hipFree(pl.bsb);
+        (void)hipFree(pl.ltw); (void)hipFree(pl.lwk); (void)hipFree(pl.lgam);
     }
     (void)hipFree(h->d_env_rows);
     if (h->pf_stream) {
@@ -1144,14 +1157,22 @@ static int env_plan_for(EchoHandle* h, int len, int smooth, EnvParams** out) {
     EchoHandle::EnvPlan e;
     std::memset(&e, 0, sizeof(e));
     e.L = len; e.smooth = smooth;
-    if (!plan_env(e.p, len, 1, 0, smooth)) return ECHO_ERR_UNSUPPORTED;
+    if (!plan_env(e.p, len, 1, 0, smooth, h->env_lin != 0)) return ECHO_ERR_UNSUPPORTED;
     std::vector<cpx<double>> er, ewn, ewl, bw, bb;
-    env_tables(e.p, er, ewn, ewl);
     int rc = ECHO_OK;
     auto up = [&](int r) { if (rc == ECHO_OK) rc = r; };
+    if (e.p.lin) {
+        std::vector<double> gam;
+        envlin_tables(len, er, ewn, gam);
+        up(dev_upload(&e.ltw, er.data(), er.size()));
+        up(dev_upload(&e.lwk, ewn.data(), ewn.size()));
+        up(dev_upload(&e.lgam, gam.data(), gam.size()));
+    } else {
+    env_tables(e.p, er, ewn, ewl);
     up(dev_upload(&e.roots, er.data(), er.size()));
     up(dev_upload(&e.wn, ewn.data(), ewn.size()));
     up(dev_upload(&e.wl, ewl.data(), ewl.size()));
+    }
     if (e.p.bs_m) {
         env_bs_tables(e.p, bw, bb);
         up(dev_upload(&e.bsw, bw.data(), bw.size()));
@@ -1160,9 +1181,11 @@ static int env_plan_for(EchoHandle* h, int len, int smooth, EnvParams** out) {
     if (rc == ECHO_OK) rc = env_kernel_prepare(e.p);
     if (rc != ECHO_OK) {
         (void)hipFree(e.roots); (void)hipFree(e.wn); (void)hipFree(e.wl); (void)hipFree(e.bsw); (void)hipFree(e.bsb);
+        (void)hipFree(e.ltw); (void)hipFree(e.lwk); (void)hipFree(e.lgam);
         return rc;
     }
     e.p.roots = e.roots; e.p.wn = e.wn; e.p.wl = e.wl; e.p.bs_w = e.bsw; e.p.bs_bhat = e.bsb;
+    e.p.lin_tw = e.ltw; e.p.lin_wk = e.lwk; e.p.lin_gam = e.lgam;
     h->env_plans.push_back(e);
     *out = &h->env_plans.back().p;
     return ECHO_OK;

@@ -12,6 +12,7 @@
 // Phases of (tid, nt) as in band_phases.h; plain C++.
 #pragma once
 #include "gfft.h"
+#include "envlin_phases.h"
 
 namespace echo {
 
@@ -59,7 +60,14 @@ struct EnvParams {
     const cpx<double>* bs_w;           // global, n: exp(-i*pi*k^2/n)
     const cpx<double>* bs_bhat;        // global, bs_m: FFT_m of the wrapped conj(w) sequence, divided by bs_m
     int stop_after;                    // development aid: leave the sequence after stage 1..5 (0 = run everything)
+    // Long signals (kEnvLinMinL <= L <= 4608) take the Hilbert transform as one real cyclic convolution of length 9216
+    // through an in-place 4608-point transform (envlin_phases.h): `plan`, roots, wn, wl and the Bluestein fields are unused.
+    int lin;
+    const cpx<double>* lin_tw;         // global, kLinTwN pass twiddles
+    const cpx<double>* lin_wk;         // global, kLinH / 2 + 1
+    const double* lin_gam;             // global, kLinH + 1
 };
+constexpr int kEnvLinMinL = 3072;      // shorter signals keep the half-length transforms (fewer points than 4608)
 
 struct EnvMisc {
     double sum_sm, max_sm, min_sm, sum_x, sum_x2, amp, sum_noise;     // first statistics pass
@@ -71,12 +79,16 @@ struct EnvMisc {
 
 constexpr int kEnvBsMaxRadix = 16;     // Bluestein: largest radix of the cyclic length's passes
 
-inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
+inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth, bool allow_lin = true) {
     p.L = L; p.n = L / 2; p.nb = nb; p.min_delay = min_delay; p.smooth = smooth; p.distance = L / 50;
     p.bs_m = 0; p.bs_w = nullptr; p.bs_bhat = nullptr;
+    p.lin = 0; p.lin_tw = nullptr; p.lin_wk = nullptr; p.lin_gam = nullptr;
     if (L % 2 != 0 || L < 8 || smooth < 1 || smooth % 2 == 0 || smooth > 9) return false;
     if (p.distance < 1) p.distance = 1;
-    if (!gfft_plan(p.plan, p.n)) {
+    p.lin = (allow_lin && L >= kEnvLinMinL && L <= kLinH) ? 1 : 0;
+    if (p.lin) {
+        p.plan.n = p.n; p.plan.npass = 0; p.plan.nroots = 0;
+    } else if (!gfft_plan(p.plan, p.n)) {
         bool found = false;
         for (int m = 2 * p.n - 1; m <= 2 * p.n + 512 && !found; ++m)
             if (gfft_plan(p.plan, m) && p.plan.radix[0] <= kEnvBsMaxRadix) { p.bs_m = m; found = true; }
@@ -103,8 +115,15 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth) {
     if (bufbytes < aux) bufbytes = aux;
     bufbytes = (bufbytes + 15) & ~15;
     int off = 0;
+    if (p.lin) {
+        // the work buffers of the later phases lie inside the transform buffer: buffer 0 over the slots that hold
+        // the result, buffer 1 behind them
+        if (bufbytes > kLinBuf1 || kLinBuf1 + bufbytes > kLinBytes || zl(p.n - 1) * 16 + 16 > kLinBuf1) return false;
+        p.off_buf0 = 0; p.off_buf1 = kLinBuf1; off = kLinBytes;
+    } else {
     p.off_buf0 = off; off += bufbytes;
     p.off_buf1 = off; off += bufbytes;
+    }
     p.off_roots = off; off += p.plan.nroots * 16;
     p.off_misc = off; off += ((int)sizeof(EnvMisc) + 15) & ~15;
     p.smem_bytes = off;
@@ -184,6 +203,55 @@ ECHO_HD EnvPart1 ph_env_load(int tid, int nt, int blk, const EnvParams& p, unsig
         m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0; m->n_kept = 0;
     }
     return a;
+}
+
+// the same for the 4608-point transform: padded slots, zeros behind the signal
+ECHO_HD EnvPart1 ph_envlin_load(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
+    cpx<double>* z = reinterpret_cast<cpx<double>*>(smem);
+    const double* x = p.corr + (size_t)blk * p.L;
+    EnvPart1 a;
+    a.v[0] = 0.0; a.v[1] = -INFINITY; a.v[2] = INFINITY; a.v[3] = 0.0; a.v[4] = 0.0; a.v[5] = 0.0; a.v[6] = 0.0;
+    cpx<double> xv[kEnvIterN];
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt, mc = m < p.n ? m : p.n - 1;
+        xv[t] = cpx<double>{x[2 * mc], x[2 * mc + 1]};
+    }
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) continue;
+        z[zl(m)] = xv[t];
+        const double a0 = fabs(xv[t].x), a1 = fabs(xv[t].y);
+        a.v[3] += xv[t].x + xv[t].y; a.v[4] += xv[t].x * xv[t].x + xv[t].y * xv[t].y;
+        a.v[5] = a0 > a.v[5] ? a0 : a.v[5]; a.v[5] = a1 > a.v[5] ? a1 : a.v[5];
+    }
+    for (int m = p.n + tid; m < kLinH; m += nt) z[zl(m)] = cpx<double>{0.0, 0.0};
+    if (tid == 0) {
+        EnvMisc* m = env_misc(smem, p);
+        m->undecided = 0; m->best_idx = -1; m->best_val = 0.0; m->n_final = 0; m->n_cand = 0; m->n_kept = 0;
+    }
+    return a;
+}
+// envelope[i] = |x[i] + i H(x)[i]|, H(x)[2m] + i H(x)[2m+1] in slot m of the transform buffer; into buffer 1
+ECHO_HD void ph_envlin_abs(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
+    const cpx<double>* v = reinterpret_cast<const cpx<double>*>(smem);
+    double* env = reinterpret_cast<double*>(env_buf(smem, p, 1));
+    const double* x = p.corr + (size_t)blk * p.L;
+    cpx<double> xv[kEnvIterN];
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt, mc = m < p.n ? m : p.n - 1;
+        xv[t] = cpx<double>{x[2 * mc], x[2 * mc + 1]};
+    }
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) continue;
+        const cpx<double> h = v[zl(m)];
+        env[2 * m] = hypot(xv[t].x, h.x);
+        env[2 * m + 1] = hypot(xv[t].y, h.y);
+    }
 }
 
 ECHO_HD void ph_env_fft_pass(int tid, int nt, const EnvParams& p, unsigned char* smem, int ps, int src, bool inv) {
@@ -675,8 +743,24 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
 #define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
     do {                                                                                                     \
         PART1_DECL;                                                                                          \
-        PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
         int cur_ = 0;                                                                                        \
+        if ((p).lin) {                                                                                       \
+            PHASE(PART1_REF = ph_envlin_load(tid, nt, blk, p, smem)) SYNC                                    \
+            if ((p).stop_after == 6) break;                                                                  \
+            PHASE(ph_envlin_pass<9, 4608, false>(tid, nt, (p).lin_tw, smem)) SYNC                            \
+            PHASE(ph_envlin_pass<8, 512, false>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC                   \
+            PHASE(ph_envlin_pass<8, 64, false>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC                    \
+            PHASE(ph_envlin_pass<8, 8, false>(tid, nt, (p).lin_tw, smem)) SYNC                               \
+            if ((p).stop_after == 1) break;                                                                  \
+            PHASE(ph_envlin_split(tid, nt, (p).lin_wk, (p).lin_gam, smem)) SYNC                              \
+            PHASE(ph_envlin_pass<8, 8, true>(tid, nt, (p).lin_tw, smem)) SYNC                                \
+            PHASE(ph_envlin_pass<8, 64, true>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC                     \
+            PHASE(ph_envlin_pass<8, 512, true>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC                    \
+            PHASE(ph_envlin_pass<9, 4608, true>(tid, nt, (p).lin_tw, smem)) SYNC                             \
+            if ((p).stop_after == 2) break;                                                                  \
+            PHASE(ph_envlin_abs(tid, nt, blk, p, smem)) SYNC                                                 \
+        } else {                                                                                             \
+        PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
         if ((p).stop_after == 6) break;                                                                      \
         ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, false)                                                  \
         if ((p).stop_after == 1) break;                                                                      \
@@ -684,6 +768,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, true)                                                   \
         if ((p).stop_after == 2) break;                                                                      \
         PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
+        }                                                                                                    \
         cur_ ^= 1;                               /* cur_: envelope */                                        \
         PHASE(ph_env_smooth(tid, nt, blk, p, smem, cur_, PART1_REF)) SYNC                                   \
         const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \

@@ -274,13 +274,20 @@ extern "C" int emul_gfft_bfly(int n, int inv, int use_float, const double* in, d
 // Envelope branch for the correlation (dsp_amd/csrc/env_phases.h), thread by thread.
 #include "../../dsp_amd/csrc/env_phases.h"
 
-extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* corr, int B, double* env_out,
-                        int* peak, double* snr, double* amp, double* quality, int* npeaks) {
+// allow_lin = 0 keeps the half-length transforms for signals the 4608-point convolution would take
+extern "C" int emul_env_opt(int L, int nb, int min_delay, int smooth, const double* corr, int B, double* env_out,
+                            int* peak, double* snr, double* amp, double* quality, int* npeaks, int allow_lin) {
     EnvParams p;
     std::memset(&p, 0, sizeof(p));
-    if (!plan_env(p, L, nb, min_delay, smooth)) return -2;
-    std::vector<cpx<double>> roots, wn, wl;
-    env_tables(p, roots, wn, wl);
+    if (!plan_env(p, L, nb, min_delay, smooth, allow_lin != 0)) return -2;
+    std::vector<cpx<double>> roots, wn, wl, ltw, lwk;
+    std::vector<double> lgam;
+    if (p.lin) {
+        envlin_tables(L, ltw, lwk, lgam);
+        p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data();
+    } else {
+        env_tables(p, roots, wn, wl);
+    }
     p.roots = roots.data(); p.wn = wn.data(); p.wl = wl.data();
     std::vector<cpx<double>> bsw, bsb;
     if (p.bs_m) { env_bs_tables(p, bsw, bsb); p.bs_w = bsw.data(); p.bs_bhat = bsb.data(); }
@@ -303,7 +310,11 @@ extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* 
         peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude;
         quality[i] = res[i].quality; npeaks[i] = res[i].n_peaks;
     }
-    return 0;
+    return p.lin ? 2 : 1;
+}
+extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* corr, int B, double* env_out,
+                        int* peak, double* snr, double* amp, double* quality, int* npeaks) {
+    return emul_env_opt(L, nb, min_delay, smooth, corr, B, env_out, peak, snr, amp, quality, npeaks, 1) > 0 ? 0 : -2;
 }
 
 // Spectrum kernel with the band-signal envelope branch (dsp_amd/csrc/hilb_phases.h): dB spectrum + signal_quality.
