@@ -95,7 +95,8 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth, boo
         if (!found) return false;
     }
     // After the smoothing the buffer that held the raw envelope is reused: first as reduction scratch (7 quantities
-    // x nt partials + fold area), then for the candidate states, the per-chunk extrema and the list of kept peaks.
+    // x nt partials of the first statistics pass, 2 x nt of the second behind them), then for the candidate states, the
+    // per-chunk extrema and the list of kept peaks (which stay below the second pass's partials).
     const int nchunk = (L + kEnvChunk - 1) / kEnvChunk;
     int aux = 0;
     p.aux_cmax = aux; aux += 5 * nchunk * 8;         // extrema of quarter chunks [4*nchunk], then of chunks [nchunk]
@@ -106,12 +107,12 @@ inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth, boo
     const int nsuper = (nchunk + kEnvSuper - 1) / kEnvSuper;
     p.aux_smax = aux; aux += nsuper * 8;
     p.aux_smin = aux; aux += nsuper * 8;
-    p.aux_side = aux; aux += 2 * kEnvMaxKept * 8;     // double side_min[kept][2]
+    p.aux_side = aux; aux += 2 * kEnvMaxKept * 8;     // double side_ok[kept][2]: 1 when that side allows the prominence
     p.aux_kept = aux; aux += kEnvMaxKept * 4;         // int candidate slot of each kept peak
     // each of the two buffers holds the transform (n, or bs_m complex doubles) and, for short signals, at least the
     // reduction scratch and the auxiliary arrays
     int bufbytes = (p.bs_m ? p.bs_m : p.n) * 16;
-    if (bufbytes < (7 * kEnvNT + 7 * 64) * 8) bufbytes = (7 * kEnvNT + 7 * 64) * 8;
+    if (bufbytes < 9 * kEnvNT * 8) bufbytes = 9 * kEnvNT * 8;        // 7 + 2 partials per thread
     if (bufbytes < aux) bufbytes = aux;
     bufbytes = (bufbytes + 15) & ~15;
     int off = 0;
@@ -363,26 +364,15 @@ ECHO_HD double red_wave(int op, double a) {
 #endif
     return a;
 }
-ECHO_HD void red_fold(int tid, int nt, double* scratch, int K, const int* ops) {
-    if (tid >= 64) return;
-    double* fold = scratch + K * nt;
-    for (int q = 0; q < K; ++q) {
+// Total of quantity q over the workgroup from the stored partials (device: one per wavefront, at the slot of its first
+// lane; host: one per thread).  Every thread that needs a total folds it by itself, in the same order: no fold phase of
+// one wavefront between two barriers.
+ECHO_HD double red_total(const double* scratch, int nt, int q, int op) {
+    double a = scratch[q * nt];
 #if defined(__HIP_DEVICE_COMPILE__)
-        double a = tid < nt / 64 ? scratch[q * nt + tid * 64] : red_identity(ops[q]);
-        a = red_wave(ops[q], a);                          // every lane ends with the total
+    for (int w = 1; w < nt / 64; ++w) a = red_op(op, a, scratch[q * nt + w * 64]);
 #else
-        double a = scratch[q * nt + tid];
-        for (int t = tid + 64; t < nt; t += 64) a = red_op(ops[q], a, scratch[q * nt + t]);
-#endif
-        fold[q * 64 + tid] = a;
-    }
-}
-ECHO_HD double red_final(const double* scratch, int nt, int K, int q, int op) {
-    const double* fold = scratch + K * nt + q * 64;
-    double a = fold[0];
-#if !defined(__HIP_DEVICE_COMPILE__)
-    const int lim = nt < 64 ? nt : 64;
-    for (int t = 1; t < lim; ++t) a = red_op(op, a, fold[t]);
+    for (int t = 1; t < nt; ++t) a = red_op(op, a, scratch[q * nt + t]);
 #endif
     return a;
 }
@@ -410,46 +400,36 @@ ECHO_HD void ph_env_part1_store(int tid, int nt, const EnvParams& p, unsigned ch
     const int ops[7] = {0, 1, 2, 0, 0, 1, 0};
     for (int q = 0; q < 7; ++q) scratch[q * nt + tid] = red_wave(ops[q], a.v[q]);
 }
-ECHO_HD void ph_env_part1_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
-    const int ops[7] = {0, 1, 2, 0, 0, 1, 0};
-    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 7, ops);
-}
-ECHO_HD void ph_env_part1_final(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
-    if (tid != 0) return;
-    const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf));
-    const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf ^ 1));
-    EnvMisc* m = env_misc(smem, p);
-    m->sum_sm = red_final(scratch, nt, 7, 0, 0); m->max_sm = red_final(scratch, nt, 7, 1, 1);
-    m->min_sm = red_final(scratch, nt, 7, 2, 2); m->sum_x = red_final(scratch, nt, 7, 3, 0);
-    m->sum_x2 = red_final(scratch, nt, 7, 4, 0); m->amp = red_final(scratch, nt, 7, 5, 1);
-    m->sum_noise = red_final(scratch, nt, 7, 6, 0);
-    m->mean_sm = m->sum_sm / (double)p.L;
-    m->mean_x = m->sum_x / (double)p.L;
-    m->mean_d = p.L > 1 ? (sm[p.L - 1] - sm[0]) / (double)(p.L - 1) : 0.0;
-}
-// second pass: squared deviations (np.std is the two-pass population deviation)
+// second pass: squared deviations (np.std is the two-pass population deviation).  The totals of the first pass are
+// folded here by every thread (the means) and by one thread for the record.
 ECHO_HD void ph_env_part2(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, int sm_buf) {
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     double* scratch = reinterpret_cast<double*>(env_buf(smem, p, sm_buf ^ 1));
-    const EnvMisc* m = env_misc(smem, p);
-    const double mean_sm = m->mean_sm, mean_d = m->mean_d;
+    EnvMisc* m = env_misc(smem, p);
+    const double sum_sm = red_total(scratch, nt, 0, 0);
+    const double mean_sm = sum_sm / (double)p.L;
+    const double mean_d = p.L > 1 ? (sm[p.L - 1] - sm[0]) / (double)(p.L - 1) : 0.0;
+    if (tid == nt - 1) {
+        m->sum_sm = sum_sm; m->max_sm = red_total(scratch, nt, 1, 1);
+        m->min_sm = red_total(scratch, nt, 2, 2); m->sum_x = red_total(scratch, nt, 3, 0);
+        m->sum_x2 = red_total(scratch, nt, 4, 0); m->amp = red_total(scratch, nt, 5, 1);
+        m->sum_noise = red_total(scratch, nt, 6, 0);
+        m->mean_sm = mean_sm; m->mean_x = m->sum_x / (double)p.L; m->mean_d = mean_d;
+    }
     double a = 0.0, c = 0.0;
     for (int i = tid; i < p.L; i += nt) {
         const double ds = sm[i] - mean_sm;
         a += ds * ds;
         if (i + 1 < p.L) { const double dd = (sm[i + 1] - sm[i]) - mean_d; c += dd * dd; }
     }
-    scratch[tid] = red_wave(0, a); scratch[nt + tid] = red_wave(0, c);
+    scratch[7 * nt + tid] = red_wave(0, a); scratch[8 * nt + tid] = red_wave(0, c);
 }
-ECHO_HD void ph_env_part2_fold(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
-    const int ops[2] = {0, 0};
-    red_fold(tid, nt, reinterpret_cast<double*>(env_buf(smem, p, scratch_buf)), 2, ops);
-}
+// totals of the second pass, by one thread of the phase that follows it
 ECHO_HD void ph_env_part2_final(int tid, int nt, const EnvParams& p, unsigned char* smem, int scratch_buf) {
-    if (tid != 0) return;
-    const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf));
+    if (tid != nt - 1) return;
+    const double* scratch = reinterpret_cast<const double*>(env_buf(smem, p, scratch_buf)) + 7 * nt;
     EnvMisc* m = env_misc(smem, p);
-    m->ss_sm = red_final(scratch, nt, 2, 0, 0); m->ss_d = red_final(scratch, nt, 2, 1, 0);
+    m->ss_sm = red_total(scratch, nt, 0, 0); m->ss_d = red_total(scratch, nt, 1, 0);
     // sum (x - mean)^2 = sum x^2 - (sum x)^2 / L: the correlation of a band-pass signal has a mean far below its
     // deviation, so nothing cancels
     m->ss_x = m->sum_x2 - m->sum_x * m->sum_x / (double)p.L;
@@ -476,6 +456,7 @@ ECHO_HD EnvCand env_cand(unsigned char* smem, const EnvParams& p, int sm_buf) {
     return c;
 }
 ECHO_HD void ph_env_candidates(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
+    ph_env_part2_final(tid, nt, p, smem, sm_buf ^ 1);       // its partials lie behind everything this phase writes
     const double* sm = reinterpret_cast<const double*>(env_buf(smem, p, sm_buf));
     double* cmax = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmax);
     double* cmin = reinterpret_cast<double*>(env_aux(smem, p, sm_buf) + p.aux_cmin);
@@ -550,10 +531,8 @@ ECHO_HD void ph_env_distance_update(int tid, int nt, const EnvParams& p, unsigne
         c.fk[t] = 0; c.fu[t] = 0;
     }
 }
-// prominence of each kept peak (scipy _peak_prominences, wlen = None).  The scan to one side runs to the first sample
-// above the peak and takes the minimum on the way; it skips whole groups of 8 chunks (512 samples), whole chunks (64)
-// and whole quarter chunks (16) whose maximum does not exceed the peak, taking their minima.  The two sides of every
-// kept peak are scanned by two threads; peaks below the required prominence (std of the envelope) are dropped.
+// prominence filter of the kept peaks (scipy _peak_prominences, wlen = None; prominence >= std of the envelope): the two
+// sides of every kept peak are walked by two threads (env_side_ok), peaks below the required prominence are dropped.
 struct EnvScan { const double *sm, *qmax, *qmin, *cmax, *cmin, *smax, *smin; int L; };
 ECHO_HD EnvScan env_scan(unsigned char* smem, const EnvParams& p, int sm_buf) {
     unsigned char* a = env_aux(smem, p, sm_buf);
@@ -566,36 +545,43 @@ ECHO_HD EnvScan env_scan(unsigned char* smem, const EnvParams& p, int sm_buf) {
     s.L = p.L;
     return s;
 }
-ECHO_HD double env_side_min(const EnvScan& s, int peak, int dir) {
+// One side of a kept peak against the required prominence: scipy's _peak_prominences walks from the peak to the first
+// sample above it (or the end of the signal) and takes the minimum on the way; the peak stays when
+// x[peak] - max(left_min, right_min) >= prominence.  Rounding is monotone, so that holds exactly when on each side some
+// sample v of the walk has fl(h - v) >= prom: the walk can stop at the first such sample (almost always within a few
+// samples of a real peak) instead of running to the end of the signal for the minimum itself.  Whole groups of 8 chunks
+// (512 samples), chunks (64) and quarter chunks (16) whose maximum does not exceed the peak are judged by their minimum.
+ECHO_HD bool env_side_ok(const EnvScan& s, int peak, int dir, double prom) {
     constexpr int Q = kEnvChunk / 4, S = kEnvChunk * kEnvSuper;
     const int L = s.L;
     const double h = s.sm[peak];
-    double mn = h;
+    if (h - h >= prom) return true;                         // the walk starts on the peak itself
     int i = peak + dir;
     while (i >= 0 && i < L) {
         const int g = i / S, gb = g * S, ge = gb + S;
         if (ge <= L && (dir < 0 ? i == ge - 1 : i == gb) && s.smax[g] <= h) {
-            mn = s.smin[g] < mn ? s.smin[g] : mn;
+            if (h - s.smin[g] >= prom) return true;
             i = dir < 0 ? gb - 1 : ge;
             continue;
         }
         const int c = i / kEnvChunk, cb = c * kEnvChunk, ce = cb + kEnvChunk;
         if (ce <= L && (dir < 0 ? i == ce - 1 : i == cb) && s.cmax[c] <= h) {
-            mn = s.cmin[c] < mn ? s.cmin[c] : mn;
+            if (h - s.cmin[c] >= prom) return true;
             i = dir < 0 ? cb - 1 : ce;
             continue;
         }
         const int q = i / Q, qb = q * Q, qe = qb + Q;
         if (qe <= L && (dir < 0 ? i == qe - 1 : i == qb) && s.qmax[q] <= h) {
-            mn = s.qmin[q] < mn ? s.qmin[q] : mn;
+            if (h - s.qmin[q] >= prom) return true;
             i = dir < 0 ? qb - 1 : qe;
             continue;
         }
-        if (s.sm[i] > h) break;
-        mn = s.sm[i] < mn ? s.sm[i] : mn;
+        const double v = s.sm[i];
+        if (v > h) break;
+        if (h - v >= prom) return true;
         i += dir;
     }
-    return mn;
+    return false;
 }
 // extrema of the groups of 8 chunks, and the list of the candidates the distance rule kept
 ECHO_HD void ph_env_kept_list(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
@@ -628,7 +614,9 @@ ECHO_HD void ph_env_side_mins(int tid, int nt, const EnvParams& p, unsigned char
     const int* kept = reinterpret_cast<const int*>(a + p.aux_kept);
     double* side = reinterpret_cast<double*>(a + p.aux_side);
     const EnvScan s = env_scan(smem, p, sm_buf);
-    for (int e = tid; e < 2 * nk; e += nt) side[e] = env_side_min(s, c.pos[kept[e >> 1]], (e & 1) ? +1 : -1);
+    const double prom = env_misc(smem, p)->std_sm;
+    for (int e = tid; e < 2 * nk; e += nt)
+        side[e] = env_side_ok(s, c.pos[kept[e >> 1]], (e & 1) ? +1 : -1, prom) ? 1.0 : 0.0;
 }
 ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned char* smem, int sm_buf) {
     unsigned char* a = env_aux(smem, p, sm_buf);
@@ -641,9 +629,7 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
         for (int t = tid; t < nc; t += nt) {
             if (c.state[t] != 2) continue;
             const int i = c.pos[t];
-            const double lmin = env_side_min(s, i, -1), rmin = env_side_min(s, i, +1);
-            const double base = lmin > rmin ? lmin : rmin;
-            if (!(s.sm[i] - base >= m->std_sm)) c.state[t] = 3;
+            if (!(env_side_ok(s, i, -1, m->std_sm) && env_side_ok(s, i, +1, m->std_sm))) c.state[t] = 3;
             else env_lds_add(&m->n_final, 1);
         }
         return;
@@ -652,9 +638,7 @@ ECHO_HD void ph_env_prominence(int tid, int nt, const EnvParams& p, unsigned cha
     const double* side = reinterpret_cast<const double*>(a + p.aux_side);
     for (int k = tid; k < nk; k += nt) {
         const int t = kept[k];
-        const double lmin = side[2 * k], rmin = side[2 * k + 1];
-        const double base = lmin > rmin ? lmin : rmin;
-        if (!(s.sm[c.pos[t]] - base >= m->std_sm)) c.state[t] = 3;
+        if (!(side[2 * k] != 0.0 && side[2 * k + 1] != 0.0)) c.state[t] = 3;
         else env_lds_add(&m->n_final, 1);
     }
 }
@@ -774,12 +758,8 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \
         if ((p).stop_after == 10) break;                                                                     \
         PHASE(ph_env_part1_store(tid, nt, p, smem, scr_, PART1_REF)) SYNC                                    \
-        PHASE(ph_env_part1_fold(tid, nt, p, smem, scr_)) SYNC                                                \
-        PHASE(ph_env_part1_final(tid, nt, p, smem, scr_)) SYNC                                               \
         if ((p).stop_after == 11) break;                                                                     \
         PHASE(ph_env_part2(tid, nt, blk, p, smem, sm_)) SYNC                                                 \
-        PHASE(ph_env_part2_fold(tid, nt, p, smem, scr_)) SYNC                                                \
-        PHASE(ph_env_part2_final(tid, nt, p, smem, scr_)) SYNC                                               \
         if ((p).stop_after == 3) break;                                                                      \
         PHASE(ph_env_candidates(tid, nt, p, smem, sm_)) SYNC                                                 \
         if ((p).stop_after == 12) break;                                                                     \
