@@ -13,6 +13,7 @@
 //     Z'[k] = E'[k] + i O'[k]            packing for the inverse, same pair
 //     z' = H * IDFT_H(Z')                the conjugate passes in reverse order: natural order out,
 //                                        H(x)[2n] + i H(x)[2n+1] in slot n
+// (the last forward pass, the pair phase and the first inverse pass run as one phase, ph_envlin_mid)
 // against two half-length transforms of length L / 2 = 2278 = 2 * 17 * 67 as 67- and 17-term sums per output: a fifth of
 // the multiply-adds.  One buffer of H complex doubles with one 16-byte pad per 16 elements (78 KB): two workgroups
 // share a compute unit's LDS.  Plain C++: phases of (tid, nt), so a host build can run them.
@@ -35,7 +36,7 @@ ECHO_HD zc zc_mulc(zc a, zc b) { return zc{fma(a.x, b.x, a.y * b.y), fma(a.y, b.
 
 // Tables: tw = pass twiddles, for the pass on blocks of S elements with radix R and stride q = S / R the runs
 // tw[off + (m - 1) q + i] = exp(-2 pi i (i m) / S), 1 <= m < R, i < q (the last pass has q = 1: none);
-// wk[k] = exp(-2 pi i k / F2), k <= H / 2;  gam[k] = Im(DFT_F2(kernel))[k] / H, k <= H.
+// wk[k] = exp(-2 pi i k / F2), k <= H;  gam[k] = Im(DFT_F2(kernel))[k] / H, k <= H.
 inline void envlin_tables(int L, std::vector<zc>& tw, std::vector<zc>& wk, std::vector<double>& gam) {
     const long double tau = 6.283185307179586476925286766559005768L;
     tw.clear();
@@ -49,8 +50,8 @@ inline void envlin_tables(int L, std::vector<zc>& tw, std::vector<zc>& wk, std::
             }
         S = q;
     }
-    wk.resize(kLinH / 2 + 1);
-    for (int k = 0; k <= kLinH / 2; ++k)
+    wk.resize(kLinH + 1);
+    for (int k = 0; k <= kLinH; ++k)
         wk[k] = zc{(double)cosl(-tau * k / kLinF2), (double)sinl(-tau * k / kLinF2)};
     // DFT_F2 of the odd kernel h[d] = g[d], h[F2 - d] = -g[d] (1 <= d < L): -2 i sum_d g[d] sin(2 pi k d / F2)
     std::vector<long double> sn(kLinF2), g(L, 0.0L);
@@ -155,39 +156,78 @@ ECHO_HD void ph_envlin_pass(int tid, int nt, const zc* tw, unsigned char* smem) 
     }
 }
 
-// real-transform unpacking, product with the kernel's spectrum, packing for the inverse: pairs (k, H - k), each owned
-// by one thread
-ECHO_HD void ph_envlin_split(int tid, int nt, const zc* wk, const double* gam, unsigned char* smem) {
+// Real-transform unpacking, product with the kernel's spectrum and packing for the inverse on one pair (k, H - k),
+// 0 < k < H, k != H / 2: zk = Z[k], zh = Z[H - k] in, Z'[k], Z'[H - k] out.
+ECHO_HD void envlin_pair(zc& zk, zc& zh, int k, const zc* wk, const double* gam) {
+    const zc w = wk[k];
+    const double gk = gam[k], gc = gam[kLinH - k];
+    // E = (Zk + conj Zh) / 2, O = -i (Zk - conj Zh) / 2
+    const zc E{0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y)};
+    const zc D{0.5 * (zk.x - zh.x), 0.5 * (zk.y + zh.y)};
+    const zc O{D.y, -D.x};
+    const zc wO = zc_mul(w, O);
+    const zc Xk{E.x + wO.x, E.y + wO.y};                               // X[k]
+    const zc Xc{E.x - wO.x, -(E.y - wO.y)};                            // X[H-k] = conj(E - w O)
+    const zc Yk{-gk * Xk.y, gk * Xk.x}, Yc{-gc * Xc.y, gc * Xc.x};     // i gam X
+    // E' = (Yk + conj Yc) / 2, O' = conj(w) (Yk - conj Yc) / 2
+    const zc Ep{0.5 * (Yk.x + Yc.x), 0.5 * (Yk.y - Yc.y)};
+    const zc Dp{0.5 * (Yk.x - Yc.x), 0.5 * (Yk.y + Yc.y)};
+    const zc Op = zc_mulc(Dp, w);
+    // Z'[k] = E' + i O',  Z'[H-k] = conj(E') + i conj(O')
+    zk = zc{Ep.x - Op.y, Ep.y + Op.x};
+    zh = zc{Ep.x + Op.y, Op.x - Ep.y};
+}
+// X[H/2] = conj Z[H/2]; Z'[H/2] = conj(i gam X)
+ECHO_HD zc envlin_mid_point(zc z, const double* gam) {
+    const double g = gam[kLinH / 2];
+    return zc{g * z.y, -(g * z.x)};
+}
+
+// The last forward pass, the pair phase and the first inverse pass in one: the last pass's butterflies take 8 contiguous
+// elements (no twiddles), and the 8 frequencies r + 576 d of the butterfly with residue r (element base
+// (r % 9) * 512 + (r / 9 % 8) * 64 + (r / 72) * 8) have their partners H - f in the butterfly with residue 576 - r, at
+// 7 - d.  A thread therefore takes both butterflies into registers, treats the 8 pairs, and runs the two conjugate
+// butterflies before it stores: two barriers and two trips through LDS less than the three phases.  Residues 0 and 288
+// pair with themselves (frequency 0 has no partner and vanishes with gam[0]; H / 2 is its own).
+ECHO_HD int envlin_res_base(int r) { return (r % 9) * 512 + ((r / 9) & 7) * 64 + (r / 72) * 8; }
+ECHO_HD void ph_envlin_mid(int tid, int nt, const zc* wk, const double* gam, unsigned char* smem) {
     zc* f = reinterpret_cast<zc*>(smem);
-    constexpr int H = kLinH;
-    for (int k = tid; k <= H / 2; k += nt) {
-        if (k == 0) { f[zl(envlin_pos(0))] = zc{0.0, 0.0}; continue; }    // gam[0] = gam[H] = 0: no mean, no Nyquist term
-        if (2 * k == H) {
-            const int ph = zl(envlin_pos(k));
-            const zc z = f[ph];                                            // X[H/2] = conj Z[H/2]
-            const double gk = gam[k];
-            const zc y{gk * z.y, gk * z.x};                                // i gam conj(z)
-            f[ph] = zc{y.x, -y.y};
-            continue;
-        }
-        const int pk = zl(envlin_pos(k)), pc = zl(envlin_pos(H - k));
-        const zc zk = f[pk], zcj = f[pc], w = wk[k];
-        const double gk = gam[k], gc = gam[H - k];
-        // E = (Zk + conj Zc) / 2, O = -i (Zk - conj Zc) / 2
-        const zc E{0.5 * (zk.x + zcj.x), 0.5 * (zk.y - zcj.y)};
-        const zc D{0.5 * (zk.x - zcj.x), 0.5 * (zk.y + zcj.y)};
-        const zc O{D.y, -D.x};
-        const zc wO = zc_mul(w, O);
-        const zc Xk{E.x + wO.x, E.y + wO.y};                               // X[k]
-        const zc Xc{E.x - wO.x, -(E.y - wO.y)};                            // X[H-k] = conj(E - w O)
-        const zc Yk{-gk * Xk.y, gk * Xk.x}, Yc{-gc * Xc.y, gc * Xc.x};     // i gam X
-        // E' = (Yk + conj Yc) / 2, O' = conj(w) (Yk - conj Yc) / 2
-        const zc Ep{0.5 * (Yk.x + Yc.x), 0.5 * (Yk.y - Yc.y)};
-        const zc Dp{0.5 * (Yk.x - Yc.x), 0.5 * (Yk.y + Yc.y)};
-        const zc Op = zc_mulc(Dp, w);
-        // Z'[k] = E' + i O',  Z'[H-k] = conj(E') + i conj(O')
-        f[pk] = zc{Ep.x - Op.y, Ep.y + Op.x};
-        f[pc] = zc{Ep.x + Op.y, Op.x - Ep.y};
+    for (int r = 1 + tid; r < 288; r += nt) {
+        const int ba = envlin_res_base(r), bb = envlin_res_base(576 - r);
+        zc v[8], u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = f[zl(ba + j)]; u[j] = f[zl(bb + j)]; }
+        envlin_bf8<false>(v); envlin_bf8<false>(u);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) envlin_pair(v[d], u[7 - d], r + 576 * d, wk, gam);
+        envlin_bf8<true>(v); envlin_bf8<true>(u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[zl(ba + j)] = v[j]; f[zl(bb + j)] = u[j]; }
+    }
+    if (tid == nt - 1) {                                   // residue 288: d pairs with 7 - d
+        const int ba = envlin_res_base(288);
+        zc v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f[zl(ba + j)];
+        envlin_bf8<false>(v);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) envlin_pair(v[d], v[7 - d], 288 + 576 * d, wk, gam);
+        envlin_bf8<true>(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[zl(ba + j)] = v[j];
+    }
+    if (tid == nt - 65) {                                  // residue 0: d pairs with 8 - d; 0 vanishes, 4 is H / 2
+        zc v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f[zl(j)];
+        envlin_bf8<false>(v);
+        v[0] = zc{0.0, 0.0};
+        v[4] = envlin_mid_point(v[4], gam);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) envlin_pair(v[d], v[8 - d], 576 * d, wk, gam);
+        envlin_bf8<true>(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[zl(j)] = v[j];
     }
 }
 

@@ -370,43 +370,60 @@ def test_emulated_fft_with_small_radix_butterflies():
 
 
 def test_emulated_envelope_branch(emul, gold_default):
-    """Correlation envelope branch (float64 Hilbert by mixed-radix FFT, uniform_filter1d(5), find_peaks with height,
-    distance and prominence, peak choice, SNR, corr_quality) and the band-signal quality that rides on the spectrum
-    kernel, thread by thread on the host, against SciPy (through the oracle) and the goldens."""
+    """Correlation envelope branch (float64 Hilbert transform, uniform_filter1d(5), find_peaks with height, distance and
+    prominence, peak choice, SNR, corr_quality) and the band-signal quality that rides on the spectrum kernel, thread by
+    thread on the host, against SciPy (through the oracle) and the goldens.  Both forms of the Hilbert transform: one
+    real cyclic convolution of length 9216 through the in-place 4608-point transform (what signals of 3072 samples and
+    more take), and the two half-length transforms (mixed-radix sums for L / 2 = 2278, Bluestein for 2141)."""
     from oracle import echo_oracle as O
     g = gold_default
     cfg = C.optimized_config()
     t = build_tables(cfg)
     P, I = ctypes.c_void_p, ctypes.c_int
-    emul.emul_env.argtypes = [I, I, I, I, P, I, P, P, P, P, P, P]
+    emul.emul_env_opt.argtypes = [I, I, I, I, P, I, P, P, P, P, P, P, I]
     corr = np.ascontiguousarray(g["stage_corr"][:6])
     B, nb, L = corr.shape
-    env = np.zeros_like(corr); peak = np.zeros((B, nb), np.int32); npk = np.zeros((B, nb), np.int32)
-    snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); q = np.zeros((B, nb))
-    assert emul.emul_env(L, nb, cfg.min_delay, 5, _ptr(corr), B, _ptr(env), _ptr(peak), _ptr(snr), _ptr(amp), _ptr(q),
-                         _ptr(npk)) == 0
     ref = g["stage_corr_envelope"][:6].astype(np.float64)
-    assert np.abs(env - ref).max() <= 2e-7 * np.abs(ref).max()
-    for f in range(B):
-        for b in range(nb):
-            e, pk, qual = O.gpu_envelope_detection(corr[f, b], 5)
-            assert np.abs(env[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
-            vp = pk[pk >= cfg.min_delay]
-            want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
-            assert (want, len(pk)) == (peak[f, b], npk[f, b])
-            assert abs(qual - q[f, b]) <= 1e-9 and amp[f, b] == np.abs(corr[f, b]).max()
-    # the band-signal call gpu_envelope_detection(band_sig, 'hilbert', 3): N = 4282 = 2 * 2141 (prime), so the
-    # half-length transforms run as Bluestein convolutions; envelope, peaks and quality against SciPy
     bs = np.ascontiguousarray(g["stage_band_sig"][:3])
     Bb, _, N = bs.shape
-    envb = np.zeros_like(bs); pk = np.zeros((Bb, nb), np.int32); npkb = np.zeros((Bb, nb), np.int32)
-    snrb = np.zeros((Bb, nb)); ampb = np.zeros((Bb, nb)); qb = np.zeros((Bb, nb))
-    assert emul.emul_env(N, nb, 0, 3, _ptr(bs), Bb, _ptr(envb), _ptr(pk), _ptr(snrb), _ptr(ampb), _ptr(qb), _ptr(npkb)) == 0
-    for f in range(Bb):
-        for b in range(nb):
-            e, pks, qual = O.gpu_envelope_detection(bs[f, b], 3)
-            assert np.abs(envb[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
-            assert len(pks) == npkb[f, b] and abs(qual - qb[f, b]) <= 1e-9
+    for allow_lin in (1, 0):
+        env = np.zeros_like(corr); peak = np.zeros((B, nb), np.int32); npk = np.zeros((B, nb), np.int32)
+        snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); q = np.zeros((B, nb))
+        assert emul.emul_env_opt(L, nb, cfg.min_delay, 5, _ptr(corr), B, _ptr(env), _ptr(peak), _ptr(snr), _ptr(amp),
+                                 _ptr(q), _ptr(npk), allow_lin) == (2 if allow_lin else 1)
+        assert np.abs(env - ref).max() <= 2e-7 * np.abs(ref).max()
+        for f in range(B):
+            for b in range(nb):
+                e, pk, qual = O.gpu_envelope_detection(corr[f, b], 5)
+                assert np.abs(env[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
+                vp = pk[pk >= cfg.min_delay]
+                want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
+                assert (want, len(pk)) == (peak[f, b], npk[f, b])
+                assert abs(qual - q[f, b]) <= 1e-9 and amp[f, b] == np.abs(corr[f, b]).max()
+        # the band-signal call gpu_envelope_detection(band_sig, 'hilbert', 3): N = 4282 = 2 * 2141 (prime), so the
+        # half-length transforms, where they are taken, run as Bluestein convolutions; envelope, peaks and quality
+        # against SciPy
+        envb = np.zeros_like(bs); pk = np.zeros((Bb, nb), np.int32); npkb = np.zeros((Bb, nb), np.int32)
+        snrb = np.zeros((Bb, nb)); ampb = np.zeros((Bb, nb)); qb = np.zeros((Bb, nb))
+        assert emul.emul_env_opt(N, nb, 0, 3, _ptr(bs), Bb, _ptr(envb), _ptr(pk), _ptr(snrb), _ptr(ampb), _ptr(qb),
+                                 _ptr(npkb), allow_lin) == (2 if allow_lin else 1)
+        for f in range(Bb):
+            for b in range(nb):
+                e, pks, qual = O.gpu_envelope_detection(bs[f, b], 3)
+                assert np.abs(envb[f, b] - e).max() <= 1e-12 * max(e.max(), 1e-300)
+                assert len(pks) == npkb[f, b] and abs(qual - qb[f, b]) <= 1e-9
+    # a signal below the 3072 samples from which the long convolution pays keeps the half-length transforms; the
+    # longest the kernel takes (4608) and an odd-half length go through the convolution
+    rng = np.random.default_rng(5)
+    for Lx, want_rc in ((3000, 1), (3072, 2), (4608, 2), (4562, 2)):
+        x = np.ascontiguousarray(rng.standard_normal((1, 1, Lx)) * np.hanning(Lx))
+        envx = np.zeros_like(x); pk1 = np.zeros((1, 1), np.int32); n1 = np.zeros((1, 1), np.int32)
+        s1 = np.zeros((1, 1)); a1 = np.zeros((1, 1)); q1 = np.zeros((1, 1))
+        assert emul.emul_env_opt(Lx, 1, 0, 5, _ptr(x), 1, _ptr(envx), _ptr(pk1), _ptr(s1), _ptr(a1), _ptr(q1), _ptr(n1),
+                                 1) == want_rc
+        e, pks, qual = O.gpu_envelope_detection(x[0, 0], 5)
+        assert np.abs(envx[0, 0] - e).max() <= 1e-12 * e.max()
+        assert len(pks) == n1[0, 0] and abs(qual - q1[0, 0]) <= 1e-9
     # signal_quality from the float32 spectrum kernel with the second Bluestein round
     emul.emul_spec_hilbert.argtypes = [I, I, I, I, P, P, P, I, P, P, I]
     band = np.ascontiguousarray(g["stage_band_sig"][:4].astype(np.float32))
