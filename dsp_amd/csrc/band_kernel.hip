@@ -20,6 +20,7 @@ __device__ unsigned long long g_stamps[kStampBlocks * kStampSlots];
 __global__ __launch_bounds__(kNT) void band_kernel(BandParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, blk = blockIdx.x;
+    if (p.skip_gate && p.skip_gate[(size_t)blk * p.skip_stride] >= 0) return;      // uniform over the workgroup
     STAMP(0);
     ph_load(tid, kNT, blk, p, smem);
     __syncthreads(); STAMP(1);

@@ -115,6 +115,10 @@ struct BandParams {
     int b2_ywlen, b2_bwlen;          // exact kernel: doubles of the y and band_sig windows of one segment
     int b2_exact_smem_bytes;
     struct B2Det* det_out;           // [B][nb] float32 maxima and candidate lags, pair kernel -> exact kernel
+    // Full chain behind the fused envelope kernel: only the (frame, band)s whose envelope branch found no peak need
+    // first_strong_peak (airSonar_optimized.py:657); a workgroup leaves at once when skip_gate[blk * skip_stride] >= 0.
+    const int32_t* skip_gate;
+    int skip_stride;
 };
 
 struct Misc {                        // lives at off_misc

@@ -70,6 +70,10 @@ struct EchoHandle {
     cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr, *d_ebsw = nullptr, *d_ebsb = nullptr;
     cpx<double> *d_eltw = nullptr, *d_elwk = nullptr; double* d_elgam = nullptr;   // Hilbert transform as one real convolution
     int env_lin = 1;                       // ECHO_ENV_LIN=0: the envelope branch keeps the half-length transforms
+    // full chain: FIR, correlation (real cyclic convolution) and envelope branch in one kernel (fce_phases.h);
+    // ECHO_FCE=0 keeps band_kernel (direct sums for every lag) + corr_env_kernel
+    cpx<double> *d_fcetw = nullptr, *d_fcewk = nullptr, *d_fceg = nullptr;
+    bool fce_ok = false;
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
     float* d_spec = nullptr;               // full chain: dB spectra when the caller does not want them
@@ -683,6 +687,19 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             h->ebase.bs_w = h->d_ebsw; h->ebase.bs_bhat = h->d_ebsb;
         }
         if (rc == ECHO_OK) rc = env_kernel_prepare(h->ebase);
+        const char* fce_env = std::getenv("ECHO_FCE");
+        if (rc == ECHO_OK && !(fce_env && std::atoi(fce_env) == 0) && cfg->iir_ncoef > 1 &&
+            plan_fce(h->ebase, cfg->n_rx, cfg->n_chirp, cfg->n_taps)) {
+            std::vector<cpx<double>> ftw, fwk, fg;
+            fce_tables(cfg->n_chirp, nb, cfg->chirps, ftw, fwk, fg);
+            up(dev_upload(&h->d_fcetw, ftw.data(), ftw.size()));
+            up(dev_upload(&h->d_fcewk, fwk.data(), fwk.size()));
+            up(dev_upload(&h->d_fceg, fg.data(), fg.size()));
+            h->ebase.fce_tw = h->d_fcetw; h->ebase.fce_wk = h->d_fcewk; h->ebase.fce_g = h->d_fceg;
+            h->ebase.taps_rev = h->d_taps_rev;
+            if (rc == ECHO_OK) rc = fce_kernel_prepare(h->ebase);
+            h->fce_ok = rc == ECHO_OK;
+        }
         if (const char* st = std::getenv("ECHO_ENV_STOP")) h->ebase.stop_after = std::atoi(st);   // development aid
         h->ebase.roots = h->d_eroots; h->ebase.wn = h->d_ewn; h->ebase.wl = h->d_ewl;
         h->has_env = rc == ECHO_OK;
@@ -724,7 +741,8 @@ void echo_destroy(EchoHandle* h) {
                     h->d_eroots, h->d_ewn, h->d_ewl, h->d_ebsw, h->d_ebsb, h->d_uk, h->d_lroots, h->d_lwn, h->d_luk, h->d_lbw, h->d_lbhat,
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw,
                     h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos,
-                    h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw, h->d_eltw, h->d_elwk, h->d_elgam};
+                    h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw, h->d_eltw, h->d_elwk, h->d_elgam,
+                    h->d_fcetw, h->d_fcewk, h->d_fceg};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
@@ -1286,7 +1304,7 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
         const double* y_in = sc.y;
         if (!ext && (f0 == 0 || inner)) h->pf_valid = false;   // consumed or discarded (a caller-scratch call leaves it alone)
         const int pre_slot = h->pf_slot;
-        bool use_side = false, track = false;
+        bool use_side = false, track = false, fce = false;
         const int side_mode = (full && !h->long_path) ? h->iir_side_full : h->iir_side;
         const int side_cus = (full && !h->long_path) ? h->iir_cus_full : h->iir_cus;
         if (!pre && side_mode && !ext && !h->capturing) {
@@ -1355,11 +1373,24 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 if (rc) return rc;
             }
         } else if (full) {
-            // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
+            double* corr = corr_out ? corr_out + (size_t)f0 * nb * h->base.L : h->d_corr;     // raw correlation: the caller's, or scratch
+            fce = h->fce_ok && (reinterpret_cast<uintptr_t>(corr) & 15) == 0;
             BandParams p = h->base;
             p.mode = MODE_Y_FIR; p.do_corr = 1; p.corr_fast = 0;
-            double* corr = corr_out ? corr_out + (size_t)f0 * nb * p.L : h->d_corr;     // raw correlation: the caller's, or scratch
             p.d_in = y_in; p.res_out = sc.res; p.corr_io = corr; p.bandf_out = sc.bandf;
+            if (fce) {
+                // FIR, correlation (one real cyclic convolution) and the envelope branch in one kernel; first_strong_peak
+                // -- direct sums over every lag in float64, the raw correlation rewritten from them -- only for the
+                // (frame, band)s whose envelope branch found no peak (airSonar_optimized.py:657)
+                EnvParams e = h->ebase;
+                e.y_in = y_in; e.bandf_out = sc.bandf; e.corr = corr; e.corr_w = corr;
+                e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
+                rc = launch_fce(e, n, s);
+                if (rc) return rc;
+                p.bandf_out = nullptr;
+                p.skip_gate = &sc.env[0].peak_idx; p.skip_stride = (int)(sizeof(EnvRes) / sizeof(int32_t));
+            }
+            // every lag in float64 (the envelope branch transforms the whole correlation), raw corr kept
             rc = launch_band(p, n, s);
             if (rc) return rc;
         } else {
@@ -1394,11 +1425,13 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
             q.spec_out = spec_db ? spec_db + (size_t)f0 * nb * q.nbins : h->d_spec;
             rc = launch_spec_hilbert(q, n, s);
             if (rc) return rc;
-            EnvParams e = h->ebase;
-            e.corr = corr_out ? corr_out + (size_t)f0 * nb * e.L : h->d_corr;
-            e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
-            rc = launch_corr_env(e, n, s);
-            if (rc) return rc;
+            if (!fce) {
+                EnvParams e = h->ebase;
+                e.corr = corr_out ? corr_out + (size_t)f0 * nb * e.L : h->d_corr;
+                e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
+                rc = launch_corr_env(e, n, s);
+                if (rc) return rc;
+            }
         } else if (spec_db) {
             BandParams q = h->base;
             q.spec_db = 1; q.specf_in = sc.bandf; q.spec_out = spec_db + (size_t)f0 * nb * q.nbins;

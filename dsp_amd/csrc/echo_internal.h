@@ -75,6 +75,8 @@ int ospec_kernel_prepare(const LongParams& p);
 int launch_long_spec_odd_ip(const LongParams& p, int B, hipStream_t s);
 int env_kernel_prepare(const EnvParams& p);
 int launch_corr_env(const EnvParams& p, int B, hipStream_t s);
+int fce_kernel_prepare(const EnvParams& p);
+int launch_fce(const EnvParams& p, int B, hipStream_t s);              // FIR + correlation + envelope branch (fce_phases.h)
 int launch_unpack_env(const EnvRes* res, int32_t* peak, double* snr, double* quality, int32_t* npeaks, int n,
                       hipStream_t s);
 int launch_synth(float* rx, const float* tx_mix, int B, int N, int M, int fs, long long first, unsigned long long seed,

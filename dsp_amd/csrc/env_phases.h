@@ -66,6 +66,18 @@ struct EnvParams {
     const cpx<double>* lin_tw;         // global, kLinTwN pass twiddles
     const cpx<double>* lin_wk;         // global, kLinH + 1
     const double* lin_gam;             // global, kLinH + 1
+    // Fused kernel of the full chain (fce_phases.h): FIR of the IIR output and the correlation as a real cyclic
+    // convolution in the same workgroup, ahead of the Hilbert transform.  `corr` is then where the kernel writes the
+    // correlation (and reads it back for the envelope).
+    int N, K, kgroups, ypad, ybuf_len; // frame length, FIR taps, groups of kR taps, zero padding of the FIR input
+    int off_ybuf, off_ctap;            // LDS: FIR input and this band's reversed taps, behind the slots of the signal
+    const double* y_in;                // [B][nb][N] zero-phase IIR output
+    const double* taps_rev;            // [nb][(kgroups + 1) * kR] reversed taps, zero padded
+    float* bandf_out;                  // optional [B][nb][N] float32 band signal (for the spectrum kernel)
+    double* corr_w;                    // [B][nb][L] == corr
+    const cpx<double>* fce_tw;         // global, kFceTwN pass twiddles of the 2304-point transform
+    const cpx<double>* fce_wk;         // global, kFceH + 1: exp(-2 pi i k / 4608)
+    const cpx<double>* fce_g;          // global, [nb][kFceH + 1]: DFT_4608(reversed chirp) / kFceH
 };
 constexpr int kEnvLinMinL = 3072;      // shorter signals keep the half-length transforms (fewer points than 4608)
 
@@ -745,34 +757,21 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         PHASE(ph_env_bs_post(tid, nt, p, smem, cur_, INV)) SYNC                                              \
     }
 
-#define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
-    do {                                                                                                     \
-        PART1_DECL;                                                                                          \
-        int cur_ = 0;                                                                                        \
-        if ((p).lin) {                                                                                       \
-            PHASE(PART1_REF = ph_envlin_load(tid, nt, blk, p, smem)) SYNC                                    \
-            if ((p).stop_after == 6) break;                                                                  \
-            PHASE(ph_envlin_pass<9, 4608, false>(tid, nt, (p).lin_tw, smem)) SYNC                            \
-            PHASE(ph_envlin_pass<8, 512, false>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC                   \
-            PHASE(ph_envlin_pass<8, 64, false>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC                    \
+// Hilbert transform of the signal in the padded slots (ph_envlin_load has run) and the raw envelope into buffer 1
+#define ECHO_ENV_LIN_HILBERT(PHASE, SYNC, p, smem, blk, nt)                                                  \
+            PHASE(ph_envlin_pass<kLinH, 9, 4608, false>(tid, nt, (p).lin_tw, smem)) SYNC                     \
+            PHASE(ph_envlin_pass<kLinH, 8, 512, false>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC            \
+            PHASE(ph_envlin_pass<kLinH, 8, 64, false>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC             \
             if ((p).stop_after == 1) break;                                                                  \
             PHASE(ph_envlin_mid(tid, nt, (p).lin_wk, (p).lin_gam, smem)) SYNC                                \
-            PHASE(ph_envlin_pass<8, 64, true>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC                     \
-            PHASE(ph_envlin_pass<8, 512, true>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC                    \
-            PHASE(ph_envlin_pass<9, 4608, true>(tid, nt, (p).lin_tw, smem)) SYNC                             \
+            PHASE(ph_envlin_pass<kLinH, 8, 64, true>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC              \
+            PHASE(ph_envlin_pass<kLinH, 8, 512, true>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC             \
+            PHASE(ph_envlin_pass<kLinH, 9, 4608, true>(tid, nt, (p).lin_tw, smem)) SYNC                      \
             if ((p).stop_after == 2) break;                                                                  \
-            PHASE(ph_envlin_abs(tid, nt, blk, p, smem)) SYNC                                                 \
-        } else {                                                                                             \
-        PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
-        if ((p).stop_after == 6) break;                                                                      \
-        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, false)                                                  \
-        if ((p).stop_after == 1) break;                                                                      \
-        PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
-        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, true)                                                   \
-        if ((p).stop_after == 2) break;                                                                      \
-        PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
-        }                                                                                                    \
-        cur_ ^= 1;                               /* cur_: envelope */                                        \
+            PHASE(ph_envlin_abs(tid, nt, blk, p, smem)) SYNC
+
+// from the raw envelope in buffer cur_ to the record
+#define ECHO_ENV_TAIL(PHASE, SYNC, PART1_REF, p, smem, blk, nt)                                              \
         PHASE(ph_env_smooth(tid, nt, blk, p, smem, cur_, PART1_REF)) SYNC                                   \
         const int sm_ = cur_ ^ 1, scr_ = cur_;   /* smoothed envelope; scratch over the raw envelope */      \
         if ((p).stop_after == 10) break;                                                                     \
@@ -798,7 +797,30 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         PHASE(ph_env_prominence(tid, nt, p, smem, sm_)) SYNC                                                 \
         if ((p).stop_after == 5) break;                                                                      \
         PHASE(ph_env_select(tid, nt, p, smem, sm_); ph_env_peaks_out(tid, nt, blk, p, smem, sm_)) SYNC        \
-        PHASE(ph_env_finish(tid, blk, p, smem))                                                              \
+        PHASE(ph_env_finish(tid, blk, p, smem))
+
+#define ECHO_ENV_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
+    do {                                                                                                     \
+        PART1_DECL;                                                                                          \
+        int cur_ = 0;                                                                                        \
+        if ((p).lin) {                                                                                       \
+            PHASE(PART1_REF = ph_envlin_load(tid, nt, blk, p, smem)) SYNC                                    \
+            if ((p).stop_after == 6) break;                                                                  \
+            ECHO_ENV_LIN_HILBERT(PHASE, SYNC, p, smem, blk, nt)                                              \
+        } else {                                                                                             \
+        PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
+        if ((p).stop_after == 6) break;                                                                      \
+        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, false)                                                  \
+        if ((p).stop_after == 1) break;                                                                      \
+        PHASE(ph_env_mid(tid, nt, p, smem, cur_)) SYNC                                                       \
+        ECHO_ENV_TRANSFORM(PHASE, SYNC, p, smem, nt, true)                                                   \
+        if ((p).stop_after == 2) break;                                                                      \
+        PHASE(ph_env_abs(tid, nt, blk, p, smem, cur_)) SYNC                                                  \
+        }                                                                                                    \
+        cur_ ^= 1;                               /* cur_: envelope */                                        \
+        ECHO_ENV_TAIL(PHASE, SYNC, PART1_REF, p, smem, blk, nt);                                             \
     } while (0)
 
 }  // namespace echo
+
+#include "fce_phases.h"

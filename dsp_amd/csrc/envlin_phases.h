@@ -124,16 +124,19 @@ template <bool INV> ECHO_HD void envlin_bf8(zc (&v)[8]) {
     for (int r = 0; r < 4; ++r) { v[2 * r] = a[r]; v[2 * r + 1] = b[r]; }
 }
 template <int R, bool INV> ECHO_HD void envlin_bf(zc (&v)[R]) {
-    if constexpr (R == 9) envlin_bf9<INV>(v); else envlin_bf8<INV>(v);
+    if constexpr (R == 9) envlin_bf9<INV>(v);
+    else if constexpr (R == 4) envlin_r4<INV>(v[0], v[1], v[2], v[3]);
+    else envlin_bf8<INV>(v);
 }
 
 // One in-place pass of radix R on blocks of S elements (stride q = S / R).  Forward: butterfly, then output m times
 // W_S^(i m); inverse: the conjugate twiddles first, then the conjugate butterfly.
-template <int R, int S, bool INV>
+// (H: length of the transform the pass belongs to.)
+template <int H, int R, int S, bool INV>
 ECHO_HD void ph_envlin_pass(int tid, int nt, const zc* tw, unsigned char* smem) {
     zc* f = reinterpret_cast<zc*>(smem);
     constexpr int q = S / R;
-    for (int t = tid; t < kLinH / R; t += nt) {
+    for (int t = tid; t < H / R; t += nt) {
         const int b = t / q, i = t - b * q, base = b * S + i;
         zc v[R], w[R];
         if (q > 1) {

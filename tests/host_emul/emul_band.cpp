@@ -317,6 +317,47 @@ extern "C" int emul_env(int L, int nb, int min_delay, int smooth, const double* 
     return emul_env_opt(L, nb, min_delay, smooth, corr, B, env_out, peak, snr, amp, quality, npeaks, 1) > 0 ? 0 : -2;
 }
 
+// Fused kernel of the full chain (dsp_amd/csrc/fce_phases.h): FIR of the IIR output y [B][nb][N], correlation as a real
+// cyclic convolution (corr_out [B][nb][L], band signal as float32 in bandf_out [B][nb][N]) and the envelope branch on it.
+extern "C" int emul_fce(int N, int M, int K, int nb, int min_delay, const double* taps, const double* chirps,
+                        const double* y, int B, double* corr_out, float* bandf_out, int* peak, double* snr, double* amp,
+                        double* quality, int* npeaks) {
+    BandParams bp;
+    std::memset(&bp, 0, sizeof(bp));
+    if (!plan_band(bp, N, M, K, nb, min_delay, 240, 0, 6.0)) return -2;
+    HostTables t;
+    build_tables(t, bp, taps, chirps);
+    EnvParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (!plan_env(p, N + M - 1, nb, min_delay, 5) || !plan_fce(p, N, M, K)) return -3;
+    std::vector<cpx<double>> ltw, lwk, ftw, fwk, fg;
+    std::vector<double> lgam;
+    envlin_tables(p.L, ltw, lwk, lgam);
+    fce_tables(M, nb, chirps, ftw, fwk, fg);
+    p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data();
+    p.fce_tw = ftw.data(); p.fce_wk = fwk.data(); p.fce_g = fg.data();
+    p.taps_rev = t.taps_rev.data(); p.y_in = y; p.bandf_out = bandf_out; p.corr = corr_out; p.corr_w = corr_out;
+    std::vector<EnvRes> res((size_t)B * nb);
+    p.res_out = res.data();
+    std::vector<unsigned char> smem(p.smem_bytes);
+    unsigned char* s = smem.data();
+    const int nt = kEnvNT;
+    std::vector<EnvPart1> part(nt);
+#define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
+#define SYNC
+    for (int blk = 0; blk < B * nb; ++blk) {
+        std::memset(s, 0xff, smem.size());
+        ECHO_FCE_SEQUENCE(PHASE, SYNC, (void)0, part[tid], p, s, blk, nt);
+    }
+#undef PHASE
+#undef SYNC
+    for (size_t i = 0; i < res.size(); ++i) {
+        peak[i] = res[i].peak_idx; snr[i] = res[i].snr_db; amp[i] = res[i].amplitude;
+        quality[i] = res[i].quality; npeaks[i] = res[i].n_peaks;
+    }
+    return 0;
+}
+
 // Spectrum kernel with the band-signal envelope branch (dsp_amd/csrc/hilb_phases.h): dB spectrum + signal_quality.
 #include "../../dsp_amd/csrc/hilb_phases.h"
 

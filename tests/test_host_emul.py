@@ -443,3 +443,36 @@ def test_emulated_envelope_branch(emul, gold_default):
     assert emul.emul_spec9(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, _ptr(taps), _ptr(chirps), _ptr(bd), 4, _ptr(spec)) == 0
     lin = 10 ** (spec.astype(np.float64) / 20)
     assert ((np.abs(lin - rl).max(axis=-1) / np.maximum(rl.max(axis=-1), 1e-300))[live] <= 1e-5).all()
+
+
+def test_emulated_fused_full_chain_kernel(emul, gold_default):
+    """FIR + correlation as one real cyclic convolution + envelope branch in one workgroup (fce_phases.h), thread by
+    thread on the host: band signal and correlation against the reference's stages in the goldens, envelope peaks,
+    SNR and quality against SciPy on the reference's correlation."""
+    from oracle import echo_oracle as O
+    g = gold_default
+    cfg = C.optimized_config()
+    t = build_tables(cfg)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    emul.emul_fce.argtypes = [I, I, I, I, I, P, P, P, I, P, P, P, P, P, P, P]
+    B, nb = 4, cfg.n_bands
+    rx = rx_from_i16(g["rx_i16"])[g["stage_frames"][:B]]
+    y = np.ascontiguousarray(np.stack([[filtfilt(f[0], f[1], x) for f in t.filters] for x in rx]))
+    taps = np.ascontiguousarray(t.taps); chirps = np.ascontiguousarray(t.chirps)
+    corr = np.zeros((B, nb, cfg.n_corr)); bandf = np.zeros((B, nb, cfg.n_rx), np.float32)
+    peak = np.zeros((B, nb), np.int32); npk = np.zeros((B, nb), np.int32)
+    snr = np.zeros((B, nb)); amp = np.zeros((B, nb)); q = np.zeros((B, nb))
+    assert emul.emul_fce(cfg.n_rx, cfg.n_chirp, cfg.FIR_TAPS, nb, cfg.min_delay, _ptr(taps), _ptr(chirps), _ptr(y), B,
+                         _ptr(corr), _ptr(bandf), _ptr(peak), _ptr(snr), _ptr(amp), _ptr(q), _ptr(npk)) == 0
+    ref_band = g["stage_band_sig"][:B].astype(np.float64)
+    ref_corr = g["stage_corr"][:B].astype(np.float64)
+    assert np.abs(bandf - ref_band).max() <= 1e-6 * np.abs(ref_band).max()
+    for f in range(B):
+        for b in range(nb):
+            scale = np.abs(ref_corr[f, b]).max()
+            assert np.abs(corr[f, b] - ref_corr[f, b]).max() <= 1e-13 * scale
+            e, pk, qual = O.gpu_envelope_detection(ref_corr[f, b], 5)
+            vp = pk[pk >= cfg.min_delay]
+            want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
+            assert (want, len(pk)) == (peak[f, b], npk[f, b])
+            assert abs(qual - q[f, b]) <= 1e-9 and abs(amp[f, b] - scale) <= 1e-13 * scale

@@ -49,6 +49,9 @@ def main():
     n_lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     variant = sys.argv[5] if len(sys.argv) > 5 else "optimized"
     legs = [("default", ("named", "full")), ("distinct", ("named", "full"))] if variant == "optimized" else [(variant, ("named",))]
+    if os.environ.get("BULK_MODES"):                        # e.g. BULK_MODES=full: only those chain modes
+        keep = os.environ["BULK_MODES"].split(",")
+        legs = [(w, tuple(m for m in modes if m in keep)) for w, modes in legs]
     from dsp_amd import config as C
     from dsp_amd.engine import BatchedKalman, EchoEngine, records_to_numpy
     from dsp_amd.synth import synth_frames
