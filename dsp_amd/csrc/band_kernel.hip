@@ -569,8 +569,6 @@ __global__ __launch_bounds__(kF9NT) void spec9_hilbert_kernel(BandParams p) {
     __syncthreads();
     ph_hilb_smooth(tid, kF9NT, blk, p, smem);
     __syncthreads();
-    ph_hilb_stats1(tid, kF9NT, p, smem);
-    __syncthreads();
     ph_hilb_dev(tid, kF9NT, blk, p, smem);
     __syncthreads();
     ph_hilb_finish(tid, kF9NT, blk, p, smem);
@@ -589,8 +587,6 @@ __global__ __launch_bounds__(kNT, 4) void spec_hilbert_kernel(BandParams p) {
     ph_hilb_env<false>(tid, kNT, blk, p, smem);
     __syncthreads();
     ph_hilb_smooth(tid, kNT, blk, p, smem);
-    __syncthreads();
-    ph_hilb_stats1(tid, kNT, p, smem);
     __syncthreads();
     ph_hilb_dev(tid, kNT, blk, p, smem);
     __syncthreads();

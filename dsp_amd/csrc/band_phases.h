@@ -126,6 +126,36 @@ struct Misc {                        // lives at off_misc
     int bidx; int pad;
 };
 
+// Fixed-order fold of a double over the 64 lanes of a wavefront, every lane ends with the total; op 0 sum, 1 max, 2 min.
+// Neighbours, pairs, the mirrored half row and the mirrored row by DPP moves (the same sets as a butterfly over
+// lane ^ 1, 2, 4, 8, and the operations commute), then the four rows' totals read as scalars: (r0 + r1) + (r2 + r3).
+// Shuffles through the LDS crossbar (__shfl_xor) cost an LDS round trip per 32-bit half and step.  The host build has no
+// wavefronts: it returns its argument and keeps one partial per thread.
+ECHO_HD double wave_fold_op(int op, double a, double b) { return op == 0 ? a + b : (op == 1 ? (a > b ? a : b) : (a < b ? a : b)); }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL> __device__ __forceinline__ double wave_fold_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_fold_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#endif
+ECHO_HD double wave_fold(int op, double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    a = wave_fold_op(op, a, wave_fold_dpp<0xB1>(a));      // quad_perm [1,0,3,2]
+    a = wave_fold_op(op, a, wave_fold_dpp<0x4E>(a));      // quad_perm [2,3,0,1]
+    a = wave_fold_op(op, a, wave_fold_dpp<0x141>(a));     // row_half_mirror
+    a = wave_fold_op(op, a, wave_fold_dpp<0x140>(a));     // row_mirror
+    const double r0 = wave_fold_lane(a, 0), r1 = wave_fold_lane(a, 16), r2 = wave_fold_lane(a, 32), r3 = wave_fold_lane(a, 48);
+    a = wave_fold_op(op, wave_fold_op(op, r0, r1), wave_fold_op(op, r2, r3));
+#endif
+    return a;
+}
+
 ECHO_HD double* lds_d(unsigned char* s, int off) { return reinterpret_cast<double*>(s + off); }
 // reduction slots of a workgroup: one per wavefront on the device, one per thread in the host emulation
 ECHO_HD int red_slots(int nt) {

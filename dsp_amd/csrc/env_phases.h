@@ -369,34 +369,7 @@ ECHO_HD double red_op(int op, double a, double b) { return op == 0 ? a + b : (op
 // On the device the per-thread partials are first folded inside each wavefront (red_wave, fixed-order butterfly), so
 // only lane 0 of a wavefront stores, and the fold reads one value per wavefront.
 ECHO_HD double red_identity(int op) { return op == 0 ? 0.0 : (op == 1 ? -INFINITY : INFINITY); }
-#if defined(__HIP_DEVICE_COMPILE__)
-// a lane's partner inside its row of 16 by a DPP move (two 32-bit halves; every lane has a valid source)
-template <int CTRL> __device__ __forceinline__ double red_dpp(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double red_lane(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                            __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-#endif
-// Fixed-order fold over the 64 lanes, every lane ends with the total: neighbours, pairs, the mirrored half row and the
-// mirrored row by DPP moves (the same sets as a butterfly over lane ^ 1, 2, 4, 8, and the operations commute), then
-// the four rows' totals read as scalars: (r0 + r1) + (r2 + r3).  (Shuffles through the LDS crossbar cost an LDS round
-// trip per 32-bit half and step.)
-ECHO_HD double red_wave(int op, double a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    a = red_op(op, a, red_dpp<0xB1>(a));                  // quad_perm [1,0,3,2]
-    a = red_op(op, a, red_dpp<0x4E>(a));                  // quad_perm [2,3,0,1]
-    a = red_op(op, a, red_dpp<0x141>(a));                 // row_half_mirror
-    a = red_op(op, a, red_dpp<0x140>(a));                 // row_mirror
-    const double r0 = red_lane(a, 0), r1 = red_lane(a, 16), r2 = red_lane(a, 32), r3 = red_lane(a, 48);
-    a = red_op(op, red_op(op, r0, r1), red_op(op, r2, r3));
-#endif
-    return a;
-}
+ECHO_HD double red_wave(int op, double a) { return wave_fold(op, a); }      // band_phases.h
 // Total of quantity q over the workgroup from the stored partials (device: one per wavefront, at the slot of its first
 // lane; host: one per thread).  Every thread that needs a total folds it by itself, in the same order: no fold phase of
 // one wavefront between two barriers.

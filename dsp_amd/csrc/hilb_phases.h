@@ -16,16 +16,20 @@ struct HilbMisc {
     double mean_sm, mean_x, mean_d;
 };
 
-// byte offsets inside the 64-KB FFT buffer, beyond the 2144 elements the second transform's output occupies
+// byte offsets inside the FFT buffer.  The second transform's output occupies the first 2144 elements; the raw envelope
+// goes behind it, the smoothed one over it (it is dead by then), the reduction scratch behind the envelope: 39.6 KB in
+// all, inside the 41.5 KB of the 4608-point transform, so that three workgroups share a compute unit's LDS as in the
+// plain spectrum kernel.
 constexpr int kHilbOffEnv = 20480;                 // float env[N]
-constexpr int kHilbOffSm = 38912;                  // float sm[N]
-constexpr int kHilbOffRed = 57344;                 // double red[5][slots] (slots = wavefronts on the device)
-                                                   // followed by HilbMisc
-constexpr int kHilbMaxN = (kHilbOffSm - kHilbOffEnv) / 4;
+constexpr int kHilbOffSm = 0;                      // float sm[N]
+constexpr int kHilbOffRed = 38912;                 // double red[8][slots] (slots = wavefronts on the device): five
+                                                   // partials of the first round, three of the second; then HilbMisc
+constexpr int kHilbRedRows = 8;
+constexpr int kHilbMaxN = (kHilbOffRed - kHilbOffEnv) / 4;
 
 // frame sizes the layout above holds: the second transform's output (n2 elements, whole 32-element swizzle blocks)
 // must end before env[], and env[] / sm[] hold N floats each
-ECHO_HD bool hilb_fits(int N, int n2) { return ((n2 + 31) & ~31) * 9 <= kHilbOffEnv && N <= kHilbMaxN && N * 4 <= kHilbOffRed - kHilbOffSm; }
+ECHO_HD bool hilb_fits(int N, int n2) { return ((n2 + 31) & ~31) * 9 <= kHilbOffEnv && N <= kHilbMaxN && N * 4 <= kHilbOffEnv - kHilbOffSm; }
 
 ECHO_HD int hilb_slots(int nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -35,7 +39,7 @@ ECHO_HD int hilb_slots(int nt) {
 #endif
 }
 ECHO_HD HilbMisc* hilb_misc(unsigned char* smem, int nt) {
-    return reinterpret_cast<HilbMisc*>(smem + kHilbOffRed + 5 * 8 * hilb_slots(nt));
+    return reinterpret_cast<HilbMisc*>(smem + kHilbOffRed + kHilbRedRows * 8 * hilb_slots(nt));
 }
 
 // LDS position of element i and the cyclic length, for the 8192-point (F9 = false) and 4608-point transforms
@@ -96,21 +100,17 @@ template <bool F9> ECHO_HD void ph_hilb_env(int tid, int nt, int blk, const Band
     }
 }
 
-// per-wavefront partials on the device, per-thread partials on the host; op 0 sum, 1 max, 2 min
-ECHO_HD void hilb_red_store(int tid, int nt, unsigned char* smem, double (&v)[5], int k, const int* ops) {
+// per-wavefront partials on the device (wave_fold, band_phases.h), per-thread partials on the host; op 0 sum, 1 max,
+// 2 min; rows row0 .. row0 + k - 1 of the scratch
+ECHO_HD void hilb_red_store(int tid, int nt, unsigned char* smem, double (&v)[5], int k, const int* ops, int row0) {
     double* red = reinterpret_cast<double*>(smem + kHilbOffRed);
     const int slots = hilb_slots(nt);
 #if defined(__HIP_DEVICE_COMPILE__)
-    for (int q = 0; q < k; ++q)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double b = __shfl_xor(v[q], o);
-            v[q] = ops[q] == 0 ? v[q] + b : (ops[q] == 1 ? (b > v[q] ? b : v[q]) : (b < v[q] ? b : v[q]));
-        }
+    for (int q = 0; q < k; ++q) v[q] = wave_fold(ops[q], v[q]);
     if ((tid & 63) == 0)
-        for (int q = 0; q < k; ++q) red[q * slots + tid / 64] = v[q];
+        for (int q = 0; q < k; ++q) red[(row0 + q) * slots + tid / 64] = v[q];
 #else
-    for (int q = 0; q < k; ++q) red[q * slots + tid] = v[q];
+    for (int q = 0; q < k; ++q) red[(row0 + q) * slots + tid] = v[q];
 #endif
 }
 ECHO_HD double hilb_red_total(int nt, const unsigned char* smem, int q, int op) {
@@ -140,23 +140,23 @@ ECHO_HD void ph_hilb_smooth(int tid, int nt, int blk, const BandParams& p, unsig
         v[3] += xd; v[4] += xd * xd;
     }
     const int ops[5] = {0, 1, 2, 0, 0};
-    hilb_red_store(tid, nt, smem, v, 5, ops);
+    hilb_red_store(tid, nt, smem, v, 5, ops, 0);
 }
-ECHO_HD void ph_hilb_stats1(int tid, int nt, const BandParams& p, unsigned char* smem) {
-    if (tid != 0) return;
-    HilbMisc* m = hilb_misc(smem, nt);
-    const float* sm = reinterpret_cast<const float*>(smem + p.off_fft + kHilbOffSm);
-    m->sum_sm = hilb_red_total(nt, smem, 0, 0); m->max_sm = hilb_red_total(nt, smem, 1, 1);
-    m->min_sm = hilb_red_total(nt, smem, 2, 2); m->sum_x = hilb_red_total(nt, smem, 3, 0);
-    m->sum_x2 = hilb_red_total(nt, smem, 4, 0);
-    m->mean_sm = m->sum_sm / (double)p.N; m->mean_x = m->sum_x / (double)p.N;
-    m->mean_d = p.N > 1 ? ((double)sm[p.N - 1] - (double)sm[0]) / (double)(p.N - 1) : 0.0;
-}
+// second round: squared deviations.  Every thread folds the first round's totals it needs (the means) by itself, one
+// thread keeps the rest for the score: no phase of one thread between two barriers.
 ECHO_HD void ph_hilb_dev(int tid, int nt, int blk, const BandParams& p, unsigned char* smem) {
     const float* sm = reinterpret_cast<const float*>(smem + p.off_fft + kHilbOffSm);
     const float* x = p.specf_in + (size_t)blk * p.N;
-    const HilbMisc* m = hilb_misc(smem, nt);
-    const double mean_sm = m->mean_sm, mean_x = m->mean_x, mean_d = m->mean_d;
+    const double sum_sm = hilb_red_total(nt, smem, 0, 0), sum_x = hilb_red_total(nt, smem, 3, 0);
+    const double mean_sm = sum_sm / (double)p.N, mean_x = sum_x / (double)p.N;
+    const double mean_d = p.N > 1 ? ((double)sm[p.N - 1] - (double)sm[0]) / (double)(p.N - 1) : 0.0;
+    if (tid == 0) {
+        HilbMisc* m = hilb_misc(smem, nt);
+        m->sum_sm = sum_sm; m->max_sm = hilb_red_total(nt, smem, 1, 1);
+        m->min_sm = hilb_red_total(nt, smem, 2, 2); m->sum_x = sum_x;
+        m->sum_x2 = hilb_red_total(nt, smem, 4, 0);
+        m->mean_sm = mean_sm; m->mean_x = mean_x; m->mean_d = mean_d;
+    }
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int i = tid; i < p.N; i += nt) {
         const double a = (double)sm[i] - mean_sm, b = (double)x[i] - mean_x;
@@ -164,7 +164,7 @@ ECHO_HD void ph_hilb_dev(int tid, int nt, int blk, const BandParams& p, unsigned
         if (i + 1 < p.N) { const double d = ((double)sm[i + 1] - (double)sm[i]) - mean_d; v[2] += d * d; }
     }
     const int ops[5] = {0, 0, 0, 0, 0};
-    hilb_red_store(tid, nt, smem, v, 3, ops);
+    hilb_red_store(tid, nt, smem, v, 3, ops, 5);
 }
 ECHO_HD double hilb_clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 // calculate_signal_quality(band_sig, envelope)
@@ -172,8 +172,8 @@ ECHO_HD void ph_hilb_finish(int tid, int nt, int blk, const BandParams& p, unsig
     if (tid != 0) return;
     const HilbMisc* m = hilb_misc(smem, nt);
     const double N = (double)p.N;
-    const double ss_sm = hilb_red_total(nt, smem, 0, 0), ss_x = hilb_red_total(nt, smem, 1, 0);
-    const double ss_d = hilb_red_total(nt, smem, 2, 0);
+    const double ss_sm = hilb_red_total(nt, smem, 5, 0), ss_x = hilb_red_total(nt, smem, 6, 0);
+    const double ss_d = hilb_red_total(nt, smem, 7, 0);
     const double std_sm = sqrt(ss_sm / N), noise = sqrt(ss_x / N);
     const double snr = 10.0 * log10((m->sum_x2 / N) / (noise * noise + 1e-10));
     const double std_d = p.N > 1 ? sqrt(ss_d / (N - 1.0)) : 0.0;

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "band_phases.h"
+#include "hilb_phases.h"
 #include "cfft_phases.h"
 #include "rcf_phases.h"
 #include "ospec_phases.h"
@@ -145,7 +146,13 @@ inline bool plan_band(BandParams& p, int N, int M, int K, int nb, int min_delay,
     p.off_fft = 0;
     p.fft9 = (2 * p.n2 - 1 <= kF9M) ? 1 : 0;
     p.spec_smem_bytes = p.fft9 ? kF9Slots * 8 : kFftM * 8;
-    p.spec_hilb_smem_bytes = kFftM * 8;                      // envelope and scratch arrays sit behind the transform
+    // envelope, smoothed envelope and reduction scratch lie inside the transform's buffer (hilb_phases.h): the
+    // 4608-point form keeps the plain spectrum kernel's footprint plus nothing
+    {
+        const int hilb_end = kHilbOffRed + kHilbRedRows * 8 * (kF9NT / 64) + (int)sizeof(HilbMisc);
+        const int f9_bytes = kF9Slots * 8;
+        p.spec_hilb_smem_bytes = p.fft9 ? align_up(f9_bytes > hilb_end ? f9_bytes : hilb_end, 16) : kFftM * 8;
+    }
     // Pair kernel + exact kernel: median detector, every lag inside one 4608-point cyclic convolution, both frames'
     // float32 FIR inputs inside the transform's buffer
     {

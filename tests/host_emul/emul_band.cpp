@@ -373,7 +373,7 @@ extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps
     if (f9 && !p.fft9) return -2;
     p.spec_db = 1; p.specf_in = bandf; p.spec_out = spec_out; p.sq_out = sq_out;
     const int nt = f9 ? kF9NT : kNT;
-    std::vector<unsigned char> smem(p.spec_hilb_smem_bytes + 5 * 8 * nt + 1024);
+    std::vector<unsigned char> smem(kFftM * 8 + kHilbRedRows * 8 * nt + 1024);     // one reduction slot per thread on the host
     unsigned char* s = smem.data();
 #define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
     auto round = [&]() {
@@ -414,7 +414,6 @@ extern "C" int emul_spec_hilbert(int N, int M, int K, int nb, const double* taps
             PHASE(ph_hilb_env<false>(tid, nt, blk, p, s));
         }
         PHASE(ph_hilb_smooth(tid, nt, blk, p, s));
-        PHASE(ph_hilb_stats1(tid, nt, p, s));
         PHASE(ph_hilb_dev(tid, nt, blk, p, s));
         PHASE(ph_hilb_finish(tid, nt, blk, p, s));
     }

@@ -131,13 +131,16 @@ def test_scheduling_switches_leave_the_bytes_alone(env, monkeypatch):
 
 @pytest.mark.parametrize("which,mode", [("original", "named"), ("twopeak", "named"), ("optimized", "full")])
 def test_lanes_with_the_confined_iir_stream(which, mode, monkeypatch):
-    """Long frames (airSonar.py's and 666.py's sizes) and the full chain of the short ones: with batches of 2048 frames
-    and more in flight on several handles the library moves every IIR to one stream confined to a share of the compute
+    """Long frames (airSonar.py's and 666.py's sizes) and the full chain of the short ones in its two-kernel form
+    (ECHO_FCE=0: band kernel + envelope kernel; the fused kernel keeps its IIR in line): with batches of 2048 frames and
+    more in flight on several handles the library moves every IIR to one stream confined to a share of the compute
     units.  Where the IIR runs changes nothing in what is computed: the lanes' bytes equal those of an engine with that
     switched off (ECHO_IIR_SIDE=0) called batch after batch."""
     from dsp_amd.engine import BatchedKalman, EchoEngine
     from dsp_amd.lanes import ChainLanes
     cfg = {"original": C.original_config, "twopeak": C.twopeak_config, "optimized": C.optimized_config}[which]()
+    if mode == "full":
+        monkeypatch.setenv("ECHO_FCE", "0")
     monkeypatch.setenv("ECHO_IIR_SIDE", "0")
     plain = EchoEngine(cfg)
     monkeypatch.delenv("ECHO_IIR_SIDE")
@@ -149,6 +152,8 @@ def test_lanes_with_the_confined_iir_stream(which, mode, monkeypatch):
             for i in range(len(sizes))]
     eng = EchoEngine(cfg)
     ln = ChainLanes(eng, 3)
+    if mode == "full":
+        monkeypatch.delenv("ECHO_FCE")
     kal2 = BatchedKalman(eng, S)
     outs = [torch.empty((n, 64), dtype=torch.uint8, device="cuda") for n in sizes]
     specs = [torch.empty((n, cfg.n_bands, cfg.n_bins), dtype=torch.float32, device="cuda") for n in sizes]

@@ -695,6 +695,38 @@ def test_full_chain_1024_frames_vs_oracle(eng_default):
                                              "avg_conf", "kalman")}, cfg)
 
 
+def test_full_chain_fused_kernel_against_the_two_kernel_form(gold_distinct, monkeypatch):
+    """The full chain's fused kernel (FIR, correlation as a real cyclic convolution, envelope branch) against its
+    two-kernel form (ECHO_FCE=0: direct sums for every lag, then the envelope kernel): same indices, validity and
+    spectra (the band signal is the same sums), floats of the records to 1e-6, the raw correlation to 1e-13 of its
+    maximum.  Where the envelope branch finds no peak -- silence, noise only: the goldens' edge frames -- the record comes
+    from first_strong_peak, which the fused form evaluates by direct sums as well: there the correlations are the same
+    bytes."""
+    from dsp_amd.engine import BatchedKalman, EchoEngine
+    cfg = C.optimized_config(C.BANDS_DISTINCT)
+    fused = EchoEngine(cfg)
+    monkeypatch.setenv("ECHO_FCE", "0")
+    plain = EchoEngine(cfg)
+    monkeypatch.delenv("ECHO_FCE")
+    rx = np.concatenate([rx_from_i16(gold_distinct["rx_i16"]), synth_frames(481, cfg, fused.tables.tx_pcm, start=4242)])
+    rf, sf, cf = fused.chain_wave(rx, n_streams=1, kalman=BatchedKalman(fused, 1))
+    rp, sp, cp = plain.chain_wave(rx, n_streams=1, kalman=BatchedKalman(plain, 1))
+    a, b = _rec(rf), _rec(rp)
+    assert np.array_equal(a["peak_idx"], b["peak_idx"]) and np.array_equal(a["valid_mask"], b["valid_mask"])
+    assert np.array_equal(a["dist"], b["dist"])
+    for k in ("snr_db", "conf", "fused_dist", "avg_conf", "kalman"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-9)
+    assert torch.equal(sf, sp)
+    cfn, cpn = cf.cpu().numpy(), cp.cpu().numpy()
+    scale = np.abs(cpn).max(axis=-1, keepdims=True)
+    assert (np.abs(cfn - cpn) <= 1e-13 * np.maximum(scale, 1e-300)).all()
+    no_peak = plain.envelope_detection(cp, want_envelope=False)["peak_idx"].cpu().numpy() < 0
+    assert no_peak.any() and not no_peak.all()
+    assert np.array_equal(cfn[no_peak], cpn[no_peak])
+    assert not np.array_equal(cfn[~no_peak], cpn[~no_peak])        # elsewhere the transforms' rounding shows
+    fused.close(); plain.close()
+
+
 @pytest.mark.parametrize("mode", ["named", "full"])
 def test_ragged_and_empty_batches(mode, eng_default):
     """Batch sizes that do not fill a tile (IIR tiles hold 16 or 64 frames), a single frame and an empty batch give
