@@ -68,11 +68,11 @@ struct EchoHandle {
     bool has_env = false;                  // envelope branch available (even correlation length with small prime factors)
     EnvParams ebase;
     cpx<double> *d_eroots = nullptr, *d_ewn = nullptr, *d_ewl = nullptr, *d_ebsw = nullptr, *d_ebsb = nullptr;
-    cpx<double> *d_eltw = nullptr, *d_elwk = nullptr; double* d_elgam = nullptr;   // Hilbert transform as one real convolution
+    cpx<double> *d_eltw = nullptr, *d_elwk = nullptr, *d_elwm = nullptr, *d_elgm = nullptr; double* d_elgam = nullptr;   // Hilbert transform as one real convolution
     int env_lin = 1;                       // ECHO_ENV_LIN=0: the envelope branch keeps the half-length transforms
     // full chain: FIR, correlation (real cyclic convolution) and envelope branch in one kernel (fce_phases.h);
     // ECHO_FCE=0 keeps band_kernel (direct sums for every lag) + corr_env_kernel
-    cpx<double> *d_fcetw = nullptr, *d_fcewk = nullptr, *d_fceg = nullptr;
+    cpx<double> *d_fcetw = nullptr, *d_fcewk = nullptr, *d_fceg = nullptr, *d_fcewm = nullptr, *d_fcegm = nullptr;
     bool fce_ok = false;
     double* d_corr = nullptr;              // full chain: raw correlation [frames][nb][L]
     double* d_sq = nullptr;                // full chain: signal_quality [frames][nb]
@@ -113,7 +113,7 @@ struct EchoHandle {
     int cap_frames = 0;
     int cap_full = 0;                      // frames the full-chain scratch (d_corr, d_sq) is sized for
     // envelope plans for signals other than the correlation (echo_envelope_rows), made on first use
-    struct EnvPlan { int L, smooth; EnvParams p; cpx<double> *roots, *wn, *wl, *bsw, *bsb, *ltw, *lwk; double* lgam; };
+    struct EnvPlan { int L, smooth; EnvParams p; cpx<double> *roots, *wn, *wl, *bsw, *bsb, *ltw, *lwk, *lwm, *lgm; double* lgam; };
     std::vector<EnvPlan> env_plans;
     EnvRes* d_env_rows = nullptr; size_t env_rows_cap = 0;
     Scratch sc;                            // allocated by ensure_scratch
@@ -670,7 +670,12 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_eltw, er.data(), er.size()));
             up(dev_upload(&h->d_elwk, ewn.data(), ewn.size()));
             up(dev_upload(&h->d_elgam, gam.data(), gam.size()));
+            std::vector<cpx<double>> wm, gm;
+            envlin_mid_tables(ewn, gam, wm, gm);
+            up(dev_upload(&h->d_elwm, wm.data(), wm.size()));
+            up(dev_upload(&h->d_elgm, gm.data(), gm.size()));
             h->ebase.lin_tw = h->d_eltw; h->ebase.lin_wk = h->d_elwk; h->ebase.lin_gam = h->d_elgam;
+            h->ebase.lin_wmid = h->d_elwm; h->ebase.lin_gmid = h->d_elgm;
         } else {
         env_tables(h->ebase, er, ewn, ewl);
         up(dev_upload(&h->d_eroots, er.data(), er.size()));
@@ -695,7 +700,12 @@ int echo_create(const EchoConfig* cfg, EchoHandle** out) {
             up(dev_upload(&h->d_fcetw, ftw.data(), ftw.size()));
             up(dev_upload(&h->d_fcewk, fwk.data(), fwk.size()));
             up(dev_upload(&h->d_fceg, fg.data(), fg.size()));
+            std::vector<cpx<double>> fwm, fgm;
+            fce_mid_tables(nb, fwk, fg, fwm, fgm);
+            up(dev_upload(&h->d_fcewm, fwm.data(), fwm.size()));
+            up(dev_upload(&h->d_fcegm, fgm.data(), fgm.size()));
             h->ebase.fce_tw = h->d_fcetw; h->ebase.fce_wk = h->d_fcewk; h->ebase.fce_g = h->d_fceg;
+            h->ebase.fce_wmid = h->d_fcewm; h->ebase.fce_gmid = h->d_fcegm;
             h->ebase.taps_rev = h->d_taps_rev;
             if (rc == ECHO_OK) rc = fce_kernel_prepare(h->ebase);
             h->fce_ok = rc == ECHO_OK;
@@ -745,12 +755,12 @@ void echo_destroy(EchoHandle* h) {
                     h->d_f9tw9, h->d_f9twa, h->d_f9twb, h->d_f9bhat, h->d_f9ghat, h->d_taps32x2, h->d_cfg, h->d_cfw2, h->d_cftw, h->d_dftw,
                     h->d_rcwh, h->d_rcwk, h->d_rcroots, h->d_rcg, h->d_rcpos,
                     h->d_ostw, h->d_osroots, h->d_osbhat, h->d_osbw, h->d_eltw, h->d_elwk, h->d_elgam,
-                    h->d_fcetw, h->d_fcewk, h->d_fceg};
+                    h->d_fcetw, h->d_fcewk, h->d_fceg, h->d_fcewm, h->d_fcegm, h->d_elwm, h->d_elgm};
     for (void* t : tabs) (void)hipFree(t);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pl : h->env_plans) {
         (void)hipFree(pl.roots); (void)hipFree(pl.wn); (void)hipFree(pl.wl); (void)hipFree(pl.bsw); (void)hipFree(pl.bsb);
-        (void)hipFree(pl.ltw); (void)hipFree(pl.lwk); (void)hipFree(pl.lgam);
+        (void)hipFree(pl.ltw); (void)hipFree(pl.lwk); (void)hipFree(pl.lgam); (void)hipFree(pl.lwm); (void)hipFree(pl.lgm);
     }
     (void)hipFree(h->d_env_rows);
     if (h->pf_stream) {
@@ -1188,6 +1198,10 @@ static int env_plan_for(EchoHandle* h, int len, int smooth, EnvParams** out) {
         up(dev_upload(&e.ltw, er.data(), er.size()));
         up(dev_upload(&e.lwk, ewn.data(), ewn.size()));
         up(dev_upload(&e.lgam, gam.data(), gam.size()));
+        std::vector<cpx<double>> wm, gm;
+        envlin_mid_tables(ewn, gam, wm, gm);
+        up(dev_upload(&e.lwm, wm.data(), wm.size()));
+        up(dev_upload(&e.lgm, gm.data(), gm.size()));
     } else {
     env_tables(e.p, er, ewn, ewl);
     up(dev_upload(&e.roots, er.data(), er.size()));
@@ -1202,11 +1216,11 @@ static int env_plan_for(EchoHandle* h, int len, int smooth, EnvParams** out) {
     if (rc == ECHO_OK) rc = env_kernel_prepare(e.p);
     if (rc != ECHO_OK) {
         (void)hipFree(e.roots); (void)hipFree(e.wn); (void)hipFree(e.wl); (void)hipFree(e.bsw); (void)hipFree(e.bsb);
-        (void)hipFree(e.ltw); (void)hipFree(e.lwk); (void)hipFree(e.lgam);
+        (void)hipFree(e.ltw); (void)hipFree(e.lwk); (void)hipFree(e.lgam); (void)hipFree(e.lwm); (void)hipFree(e.lgm);
         return rc;
     }
     e.p.roots = e.roots; e.p.wn = e.wn; e.p.wl = e.wl; e.p.bs_w = e.bsw; e.p.bs_bhat = e.bsb;
-    e.p.lin_tw = e.ltw; e.p.lin_wk = e.lwk; e.p.lin_gam = e.lgam;
+    e.p.lin_tw = e.ltw; e.p.lin_wk = e.lwk; e.p.lin_gam = e.lgam; e.p.lin_wmid = e.lwm; e.p.lin_gmid = e.lgm;
     h->env_plans.push_back(e);
     *out = &h->env_plans.back().p;
     return ECHO_OK;

@@ -66,6 +66,8 @@ struct EnvParams {
     const cpx<double>* lin_tw;         // global, kLinTwN pass twiddles
     const cpx<double>* lin_wk;         // global, kLinH + 1
     const double* lin_gam;             // global, kLinH + 1
+    const cpx<double>* lin_wmid;       // global, 8 * 288: lin_wk in the middle phase's lane order
+    const cpx<double>* lin_gmid;       // global, 8 * 288: (gam[k], gam[H - k]) in that order
     // Fused kernel of the full chain (fce_phases.h): FIR of the IIR output and the correlation as a real cyclic
     // convolution in the same workgroup, ahead of the Hilbert transform.  `corr` is then where the kernel writes the
     // correlation (and reads it back for the envelope).
@@ -78,6 +80,8 @@ struct EnvParams {
     const cpx<double>* fce_tw;         // global, kFceTwN pass twiddles of the 2304-point transform
     const cpx<double>* fce_wk;         // global, kFceH + 1: exp(-2 pi i k / 4608)
     const cpx<double>* fce_g;          // global, [nb][kFceH + 1]: DFT_4608(reversed chirp) / kFceH
+    const cpx<double>* fce_wmid;       // global, 8 * 144: fce_wk in the middle phase's lane order
+    const cpx<double>* fce_gmid;       // global, [nb][8 * 144][2]: (g[k], g[H - k]) in that order
 };
 constexpr int kEnvLinMinL = 3072;      // shorter signals keep the half-length transforms (fewer points than 4608)
 
@@ -94,7 +98,7 @@ constexpr int kEnvBsMaxRadix = 16;     // Bluestein: largest radix of the cyclic
 inline bool plan_env(EnvParams& p, int L, int nb, int min_delay, int smooth, bool allow_lin = true) {
     p.L = L; p.n = L / 2; p.nb = nb; p.min_delay = min_delay; p.smooth = smooth; p.distance = L / 50;
     p.bs_m = 0; p.bs_w = nullptr; p.bs_bhat = nullptr;
-    p.lin = 0; p.lin_tw = nullptr; p.lin_wk = nullptr; p.lin_gam = nullptr;
+    p.lin = 0; p.lin_tw = nullptr; p.lin_wk = nullptr; p.lin_gam = nullptr; p.lin_wmid = nullptr; p.lin_gmid = nullptr;
     if (L % 2 != 0 || L < 8 || smooth < 1 || smooth % 2 == 0 || smooth > 9) return false;
     if (p.distance < 1) p.distance = 1;
     p.lin = (allow_lin && L >= kEnvLinMinL && L <= kLinH) ? 1 : 0;
@@ -736,7 +740,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
             PHASE(ph_envlin_pass<kLinH, 8, 512, false>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC            \
             PHASE(ph_envlin_pass<kLinH, 8, 64, false>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC             \
             if ((p).stop_after == 1) break;                                                                  \
-            PHASE(ph_envlin_mid(tid, nt, (p).lin_wk, (p).lin_gam, smem)) SYNC                                \
+            PHASE(ph_envlin_mid(tid, nt, (p).lin_wk, (p).lin_gam, (p).lin_wmid, (p).lin_gmid, smem)) SYNC      \
             PHASE(ph_envlin_pass<kLinH, 8, 64, true>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC              \
             PHASE(ph_envlin_pass<kLinH, 8, 512, true>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC             \
             PHASE(ph_envlin_pass<kLinH, 9, 4608, true>(tid, nt, (p).lin_tw, smem)) SYNC                      \

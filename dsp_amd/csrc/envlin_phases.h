@@ -37,6 +37,20 @@ ECHO_HD zc zc_mulc(zc a, zc b) { return zc{fma(a.x, b.x, a.y * b.y), fma(a.y, b.
 // Tables: tw = pass twiddles, for the pass on blocks of S elements with radix R and stride q = S / R the runs
 // tw[off + (m - 1) q + i] = exp(-2 pi i (i m) / S), 1 <= m < R, i < q (the last pass has q = 1: none);
 // wk[k] = exp(-2 pi i k / F2), k <= H;  gam[k] = Im(DFT_F2(kernel))[k] / H, k <= H.
+// lane order of the middle phase: item t = (d2 = t & 3, d1 = (t >> 2) & 7, d0 = t >> 5) is the residue d0 + 9 d1 + 72 d2
+inline int envlin_mid_residue(int t) { return (t >> 5) + 9 * ((t >> 2) & 7) + 72 * (t & 3); }
+// wmid[d * 288 + t] = wk[k], gmid[d * 288 + t] = (gam[k], gam[H - k]) for k = residue(t) + 576 d: what the middle phase
+// reads, in the order its lanes read it
+inline void envlin_mid_tables(const std::vector<zc>& wk, const std::vector<double>& gam, std::vector<zc>& wmid,
+                              std::vector<zc>& gmid) {
+    wmid.assign(8 * 288, zc{0.0, 0.0}); gmid.assign(8 * 288, zc{0.0, 0.0});
+    for (int t = 1; t < 288; ++t)
+        for (int d = 0; d < 8; ++d) {
+            const int k = envlin_mid_residue(t) + 576 * d;
+            wmid[d * 288 + t] = wk[k];
+            gmid[d * 288 + t] = zc{gam[k], gam[kLinH - k]};
+        }
+}
 inline void envlin_tables(int L, std::vector<zc>& tw, std::vector<zc>& wk, std::vector<double>& gam) {
     const long double tau = 6.283185307179586476925286766559005768L;
     tw.clear();
@@ -161,9 +175,7 @@ ECHO_HD void ph_envlin_pass(int tid, int nt, const zc* tw, unsigned char* smem) 
 
 // Real-transform unpacking, product with the kernel's spectrum and packing for the inverse on one pair (k, H - k),
 // 0 < k < H, k != H / 2: zk = Z[k], zh = Z[H - k] in, Z'[k], Z'[H - k] out.
-ECHO_HD void envlin_pair(zc& zk, zc& zh, int k, const zc* wk, const double* gam) {
-    const zc w = wk[k];
-    const double gk = gam[k], gc = gam[kLinH - k];
+ECHO_HD void envlin_pair(zc& zk, zc& zh, zc w, double gk, double gc) {
     // E = (Zk + conj Zh) / 2, O = -i (Zk - conj Zh) / 2
     const zc E{0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y)};
     const zc D{0.5 * (zk.x - zh.x), 0.5 * (zk.y + zh.y)};
@@ -193,16 +205,26 @@ ECHO_HD zc envlin_mid_point(zc z, const double* gam) {
 // butterflies before it stores: two barriers and two trips through LDS less than the three phases.  Residues 0 and 288
 // pair with themselves (frequency 0 has no partner and vanishes with gam[0]; H / 2 is its own).
 ECHO_HD int envlin_res_base(int r) { return (r % 9) * 512 + ((r / 9) & 7) * 64 + (r / 72) * 8; }
-ECHO_HD void ph_envlin_mid(int tid, int nt, const zc* wk, const double* gam, unsigned char* smem) {
+ECHO_HD void ph_envlin_mid(int tid, int nt, const zc* wk, const double* gam, const zc* wmid, const zc* gmid,
+                           unsigned char* smem) {
     zc* f = reinterpret_cast<zc*>(smem);
-    for (int r = 1 + tid; r < 288; r += nt) {
-        const int ba = envlin_res_base(r), bb = envlin_res_base(576 - r);
+    // The residues below 288 are those whose butterfly starts in the first half of its 64-element block (r = d0 +
+    // 9 d1 + 72 d2 at element 512 d0 + 64 d1 + 8 d2, d2 < 4).  Consecutive lanes take consecutive d2, then d1, then d0:
+    // butterflies 8 and 64 elements apart fall into different LDS banks, butterflies 512 apart into the same ones
+    // (consecutive residues would put a wavefront's 16-byte reads nine to a bank).
+    for (int t = 1 + tid; t < 288; t += nt) {
+        const int d2 = t & 3, d1 = (t >> 2) & 7, d0 = t >> 5;
+        const int r = d0 + 9 * d1 + 72 * d2;
+        const int ba = d0 * 512 + d1 * 64 + d2 * 8, bb = envlin_res_base(576 - r);
         zc v[8], u[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = f[zl(ba + j)]; u[j] = f[zl(bb + j)]; }
         envlin_bf8<false>(v); envlin_bf8<false>(u);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) envlin_pair(v[d], u[7 - d], r + 576 * d, wk, gam);
+        for (int d = 0; d < 8; ++d) {
+            const zc g2 = gmid[d * 288 + t];
+            envlin_pair(v[d], u[7 - d], wmid[d * 288 + t], g2.x, g2.y);
+        }
         envlin_bf8<true>(v); envlin_bf8<true>(u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { f[zl(ba + j)] = v[j]; f[zl(bb + j)] = u[j]; }
@@ -214,7 +236,10 @@ ECHO_HD void ph_envlin_mid(int tid, int nt, const zc* wk, const double* gam, uns
         for (int j = 0; j < 8; ++j) v[j] = f[zl(ba + j)];
         envlin_bf8<false>(v);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) envlin_pair(v[d], v[7 - d], 288 + 576 * d, wk, gam);
+        for (int d = 0; d < 4; ++d) {
+            const int k = 288 + 576 * d;
+            envlin_pair(v[d], v[7 - d], wk[k], gam[k], gam[kLinH - k]);
+        }
         envlin_bf8<true>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[zl(ba + j)] = v[j];
@@ -227,7 +252,7 @@ ECHO_HD void ph_envlin_mid(int tid, int nt, const zc* wk, const double* gam, uns
         v[0] = zc{0.0, 0.0};
         v[4] = envlin_mid_point(v[4], gam);
 #pragma unroll
-        for (int d = 1; d < 4; ++d) envlin_pair(v[d], v[8 - d], 576 * d, wk, gam);
+        for (int d = 1; d < 4; ++d) envlin_pair(v[d], v[8 - d], wk[576 * d], gam[576 * d], gam[kLinH - 576 * d]);
         envlin_bf8<true>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[zl(j)] = v[j];

@@ -39,6 +39,23 @@ inline bool plan_fce(EnvParams& p, int N, int M, int K) {
 
 // tw: pass twiddles as in envlin_tables for the passes (S, R) = (2304, 4), (576, 9), (64, 8); wk[k] = exp(-2 pi i k / 4608),
 // k <= 2304; g[band][k] = DFT_4608(reversed chirp of the band)[k] / 2304, k <= 2304.
+// lane order of the middle phase: item t = (d2 = t & 3, d1 = (t >> 2) % 9, d0 = (t >> 2) / 9) is the residue
+// d0 + 4 d1 + 36 d2
+inline int fce_mid_residue(int t) { return (t >> 2) / 9 + 4 * ((t >> 2) % 9) + 36 * (t & 3); }
+// wmid[d * 144 + t] = wk[k]; gmid[(band * 8 + d) * 144 + t][2] = g[band][k], g[band][H - k], k = residue(t) + 288 d
+inline void fce_mid_tables(int nb, const std::vector<zc>& wk, const std::vector<zc>& g, std::vector<zc>& wmid,
+                           std::vector<zc>& gmid) {
+    wmid.assign(8 * 144, zc{0.0, 0.0}); gmid.assign((size_t)nb * 8 * 144 * 2, zc{0.0, 0.0});
+    for (int t = 1; t < 144; ++t)
+        for (int d = 0; d < 8; ++d) {
+            const int k = fce_mid_residue(t) + 288 * d;
+            wmid[d * 144 + t] = wk[k];
+            for (int b = 0; b < nb; ++b) {
+                gmid[(((size_t)b * 8 + d) * 144 + t) * 2] = g[(size_t)b * (kFceH + 1) + k];
+                gmid[(((size_t)b * 8 + d) * 144 + t) * 2 + 1] = g[(size_t)b * (kFceH + 1) + kFceH - k];
+            }
+        }
+}
 inline void fce_tables(int M, int nb, const double* chirps, std::vector<zc>& tw, std::vector<zc>& wk, std::vector<zc>& g) {
     const long double tau = 6.283185307179586476925286766559005768L;
     tw.clear();
@@ -145,8 +162,7 @@ ECHO_HD void ph_fce_pass0(int tid, int nt, int blk, const EnvParams& p, unsigned
     }
 }
 // pair (k, H - k) of the 2304-point transform: unpack, multiply by the reversed chirp's spectrum, pack for the inverse
-ECHO_HD void fce_pair(zc& zk, zc& zh, int k, const zc* wk, const zc* g) {
-    const zc w = wk[k], gk = g[k], gc = g[kFceH - k];
+ECHO_HD void fce_pair(zc& zk, zc& zh, zc w, zc gk, zc gc) {
     const zc E{0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y)};
     const zc D{0.5 * (zk.x - zh.x), 0.5 * (zk.y + zh.y)};
     const zc O{D.y, -D.x};
@@ -166,14 +182,21 @@ ECHO_HD void ph_fce_mid(int tid, int nt, int blk, const EnvParams& p, unsigned c
     zc* f = reinterpret_cast<zc*>(smem);
     const zc* wk = p.fce_wk;
     const zc* g = p.fce_g + (size_t)(blk % p.nb) * (kFceH + 1);
-    for (int r = 1 + tid; r < 144; r += nt) {
-        const int ba = fce_res_base(r), bb = fce_res_base(288 - r);
+    const zc* wmid = p.fce_wmid;
+    const zc* gmid = p.fce_gmid + (size_t)(blk % p.nb) * 8 * 144 * 2;
+    // residues below 144 = butterflies in the first half of their 64-element block (r = d0 + 4 d1 + 36 d2 at element
+    // 576 d0 + 64 d1 + 8 d2, d2 < 4); lanes run over d2, then d1, then d0 (LDS banks, as in ph_envlin_mid)
+    for (int t = 1 + tid; t < 144; t += nt) {
+        const int d2 = t & 3, q = t >> 2, d1 = q % 9, d0 = q / 9;
+        const int r = d0 + 4 * d1 + 36 * d2;                // == fce_mid_residue(t)
+        const int ba = d0 * 576 + d1 * 64 + d2 * 8, bb = fce_res_base(288 - r);
         zc v[8], u[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = f[zl(ba + j)]; u[j] = f[zl(bb + j)]; }
         envlin_bf8<false>(v); envlin_bf8<false>(u);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) fce_pair(v[d], u[7 - d], r + 288 * d, wk, g);
+        for (int d = 0; d < 8; ++d)
+            fce_pair(v[d], u[7 - d], wmid[d * 144 + t], gmid[(d * 144 + t) * 2], gmid[(d * 144 + t) * 2 + 1]);
         envlin_bf8<true>(v); envlin_bf8<true>(u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { f[zl(ba + j)] = v[j]; f[zl(bb + j)] = u[j]; }
@@ -185,7 +208,10 @@ ECHO_HD void ph_fce_mid(int tid, int nt, int blk, const EnvParams& p, unsigned c
         for (int j = 0; j < 8; ++j) v[j] = f[zl(ba + j)];
         envlin_bf8<false>(v);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) fce_pair(v[d], v[7 - d], 144 + 288 * d, wk, g);
+        for (int d = 0; d < 4; ++d) {
+            const int k = 144 + 288 * d;
+            fce_pair(v[d], v[7 - d], wk[k], g[k], g[kFceH - k]);
+        }
         envlin_bf8<true>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[zl(ba + j)] = v[j];
@@ -202,7 +228,7 @@ ECHO_HD void ph_fce_mid(int tid, int nt, int blk, const EnvParams& p, unsigned c
             v[4] = zc{y.x, -y.y};
         }
 #pragma unroll
-        for (int d = 1; d < 4; ++d) fce_pair(v[d], v[8 - d], 288 * d, wk, g);
+        for (int d = 1; d < 4; ++d) fce_pair(v[d], v[8 - d], wk[288 * d], g[288 * d], g[kFceH - 288 * d]);
         envlin_bf8<true>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[zl(j)] = v[j];

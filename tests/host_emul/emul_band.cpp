@@ -280,11 +280,12 @@ extern "C" int emul_env_opt(int L, int nb, int min_delay, int smooth, const doub
     EnvParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_env(p, L, nb, min_delay, smooth, allow_lin != 0)) return -2;
-    std::vector<cpx<double>> roots, wn, wl, ltw, lwk;
+    std::vector<cpx<double>> roots, wn, wl, ltw, lwk, lwm, lgm;
     std::vector<double> lgam;
     if (p.lin) {
         envlin_tables(L, ltw, lwk, lgam);
-        p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data();
+        envlin_mid_tables(lwk, lgam, lwm, lgm);
+        p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data(); p.lin_wmid = lwm.data(); p.lin_gmid = lgm.data();
     } else {
         env_tables(p, roots, wn, wl);
     }
@@ -330,12 +331,14 @@ extern "C" int emul_fce(int N, int M, int K, int nb, int min_delay, const double
     EnvParams p;
     std::memset(&p, 0, sizeof(p));
     if (!plan_env(p, N + M - 1, nb, min_delay, 5) || !plan_fce(p, N, M, K)) return -3;
-    std::vector<cpx<double>> ltw, lwk, ftw, fwk, fg;
+    std::vector<cpx<double>> ltw, lwk, lwm, lgm, ftw, fwk, fg, fwm, fgm;
     std::vector<double> lgam;
     envlin_tables(p.L, ltw, lwk, lgam);
+    envlin_mid_tables(lwk, lgam, lwm, lgm);
     fce_tables(M, nb, chirps, ftw, fwk, fg);
-    p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data();
-    p.fce_tw = ftw.data(); p.fce_wk = fwk.data(); p.fce_g = fg.data();
+    fce_mid_tables(nb, fwk, fg, fwm, fgm);
+    p.lin_tw = ltw.data(); p.lin_wk = lwk.data(); p.lin_gam = lgam.data(); p.lin_wmid = lwm.data(); p.lin_gmid = lgm.data();
+    p.fce_tw = ftw.data(); p.fce_wk = fwk.data(); p.fce_g = fg.data(); p.fce_wmid = fwm.data(); p.fce_gmid = fgm.data();
     p.taps_rev = t.taps_rev.data(); p.y_in = y; p.bandf_out = bandf_out; p.corr = corr_out; p.corr_w = corr_out;
     std::vector<EnvRes> res((size_t)B * nb);
     p.res_out = res.data();
