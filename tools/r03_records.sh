@@ -12,8 +12,10 @@ b bench_1M_frames_sharded_job --total-frames 1000000 --steps 5 --warmup 1 || exi
 b bench_1M_frames_sharded_job_force_dist --total-frames 1000000 --steps 5 --warmup 1 --force-dist || exit 1
 b bench_no_spectra --no-spectra || exit 1
 b bench_unoverlapped --no-pipeline || exit 1
-b bench_full_mode --mode full --lanes 1 || exit 1
-b bench_full_mode_driver_protocol --mode full --lanes 1 --steps 20 --warmup 5 || exit 1
+b bench_full_mode --mode full || exit 1
+b bench_full_mode_driver_protocol --mode full --steps 20 --warmup 5 || exit 1
+ECHO_FCE=0 b bench_full_mode_two_kernels --mode full || exit 1
+ECHO_ENV_LIN=0 b bench_full_mode_half_length_transforms --mode full || exit 1
 b bench_original_variant --workload original || exit 1
 b bench_original_variant_driver_protocol --workload original --steps 20 --warmup 5 || exit 1
 b bench_twopeak_variant --workload twopeak --lanes 1 || exit 1
