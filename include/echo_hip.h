@@ -250,7 +250,12 @@ int echo_chain(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db,
  * the envelope peak at or beyond min_delay as peak_idx (an index into corr) with the envelope SNR (:647-654), else
  * the first_strong_peak result (:657); amplitude = max|corr| of whichever corr that path leaves (:666); confidence
  * scaled by 0.5 + 0.5 * (signal_quality + corr_quality) / 2 (:670-671); then fusion and Kalman as echo_chain.
- * quality (optional) receives [B][nb][2] = signal_quality, corr_quality.  Other arguments as echo_chain. */
+ * quality (optional) receives [B][nb][2] = signal_quality, corr_quality.  Other arguments as echo_chain.
+ * For the reference's sizes (correlations of 3072 to 4608 lags) the band stage and the envelope branch are one kernel:
+ * the correlation and the Hilbert transform run as real cyclic convolutions (values within about 1e-16 of the
+ * correlation's maximum of the direct sums), which decides the envelope peaks exactly as SciPy does on every frame
+ * checked (1.8 million frame-bands against the reference's chain); where the envelope branch finds no peak and the
+ * record comes from first_strong_peak, that (frame, band) is evaluated by direct sums as echo_chain does. */
 int echo_chain_full(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* quality,
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init,
                     int B, int n_streams, void* stream);
@@ -270,7 +275,9 @@ int echo_chain_ordered(EchoHandle* h, const float* rx, EchoResult* out, float* s
  * of echo_chain_full (what the log line :741-743, distanceSig :745 and the CSV row :746-747 are made of) plus the
  * waveSig arrays of every frame: spec_db[B][nb][N/2+1] ('band_spectra', :710, :752) and corr[B][nb][N+M-1], the raw
  * correlations ('correlations', :712, :753; float64, unmodified: the envelope path of _process_band_gpu does not write
- * into its corr, and process_band_with_output keeps its own).  Both are required; other arguments as echo_chain_full. */
+ * into its corr, and process_band_with_output keeps its own; they equal echo_correlate's direct sums to about 1e-16 of
+ * each row's maximum, and exactly where the record comes from first_strong_peak).  Both are required; other arguments
+ * as echo_chain_full. */
 int echo_chain_wave(EchoHandle* h, const float* rx, EchoResult* out, float* spec_db, double* corr, double* quality,
                     double* kalman_x, double* kalman_p, uint8_t* kalman_init, int B, int n_streams, void* stream);
 

@@ -38,3 +38,9 @@ def test_no_kernel_uses_scratch():
     # the float64 envelope kernel runs four waves per SIMD: it must stay within 128 registers
     env = [v for k, v in res.items() if "corr_env_kernel" in k]
     assert env and env[0]["VGPRs"] <= 128, env
+    # so does the fused FIR + correlation + envelope kernel of the full chain (two workgroups of eight waves per unit)
+    fce = [v for k, v in res.items() if "fce_kernel" in k]
+    assert fce and fce[0]["VGPRs"] <= 128, fce
+    # the spectrum + band-signal quality kernel shares a compute unit three workgroups of nine waves at a time
+    sh = [v for k, v in res.items() if "spec9_hilbert_kernel" in k]
+    assert sh and sh[0]["VGPRs"] <= 72, sh
