@@ -1400,7 +1400,8 @@ static int chain_impl(EchoHandle* h, const float* rx, EchoResult* out, float* sp
                 // -- direct sums over every lag in float64, the raw correlation rewritten from them -- only for the
                 // (frame, band)s whose envelope branch found no peak (airSonar_optimized.py:657)
                 EnvParams e = h->ebase;
-                e.y_in = y_in; e.bandf_out = sc.bandf; e.corr = corr; e.corr_w = corr;
+                // the raw correlation leaves the kernel only for a caller who asked for it
+                e.y_in = y_in; e.bandf_out = sc.bandf; e.corr = corr; e.corr_w = corr_out ? corr : nullptr;
                 e.env_out = nullptr; e.res_out = sc.env; e.peaks_out = nullptr;
                 rc = launch_fce(e, n, s);
                 if (rc) return rc;

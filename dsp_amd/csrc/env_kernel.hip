@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kEnvNT, 4) void fce_kernel(EnvParams p) {
     const int tid = threadIdx.x, blk = blockIdx.x;
 #define ECHO_PHASE(...) { __VA_ARGS__; }
 #define ECHO_SYNC __syncthreads();
-    ECHO_FCE_SEQUENCE(ECHO_PHASE, ECHO_SYNC, EnvPart1 part1_, part1_, p, smem, blk, kEnvNT);
+    ECHO_FCE_SEQUENCE(ECHO_PHASE, ECHO_SYNC, EnvPart1 part1_, part1_, FceKeep keep_, keep_, p, smem, blk, kEnvNT);
 #undef ECHO_PHASE
 #undef ECHO_SYNC
 }

@@ -734,7 +734,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
         PHASE(ph_env_bs_post(tid, nt, p, smem, cur_, INV)) SYNC                                              \
     }
 
-// Hilbert transform of the signal in the padded slots (ph_envlin_load has run) and the raw envelope into buffer 1
+// Hilbert transform of the signal in the padded slots (ph_envlin_load has run); the raw envelope follows
 #define ECHO_ENV_LIN_HILBERT(PHASE, SYNC, p, smem, blk, nt)                                                  \
             PHASE(ph_envlin_pass<kLinH, 9, 4608, false>(tid, nt, (p).lin_tw, smem)) SYNC                     \
             PHASE(ph_envlin_pass<kLinH, 8, 512, false>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC            \
@@ -744,8 +744,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
             PHASE(ph_envlin_pass<kLinH, 8, 64, true>(tid, nt, (p).lin_tw + kLinTw2, smem)) SYNC              \
             PHASE(ph_envlin_pass<kLinH, 8, 512, true>(tid, nt, (p).lin_tw + kLinTw1, smem)) SYNC             \
             PHASE(ph_envlin_pass<kLinH, 9, 4608, true>(tid, nt, (p).lin_tw, smem)) SYNC                      \
-            if ((p).stop_after == 2) break;                                                                  \
-            PHASE(ph_envlin_abs(tid, nt, blk, p, smem)) SYNC
+            if ((p).stop_after == 2) break;
 
 // from the raw envelope in buffer cur_ to the record
 #define ECHO_ENV_TAIL(PHASE, SYNC, PART1_REF, p, smem, blk, nt)                                              \
@@ -784,6 +783,7 @@ ECHO_HD void ph_env_finish(int tid, int blk, const EnvParams& p, unsigned char* 
             PHASE(PART1_REF = ph_envlin_load(tid, nt, blk, p, smem)) SYNC                                    \
             if ((p).stop_after == 6) break;                                                                  \
             ECHO_ENV_LIN_HILBERT(PHASE, SYNC, p, smem, blk, nt)                                              \
+            PHASE(ph_envlin_abs(tid, nt, blk, p, smem)) SYNC                                                 \
         } else {                                                                                             \
         PHASE(PART1_REF = ph_env_load(tid, nt, blk, p, smem)) SYNC                                                       \
         if ((p).stop_after == 6) break;                                                                      \

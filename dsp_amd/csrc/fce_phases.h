@@ -234,17 +234,23 @@ ECHO_HD void ph_fce_mid(int tid, int nt, int blk, const EnvParams& p, unsigned c
         for (int j = 0; j < 8; ++j) f[zl(j)] = v[j];
     }
 }
-// slot m now holds corr[2m] + i corr[2m+1]: the correlation leaves for global memory (the envelope reads it back, and
-// it is the chain's raw correlation), its statistics start, and the slots behind it are cleared for the Hilbert
-// transform, which finds its input in place
-ECHO_HD EnvPart1 ph_fce_corr_out(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem) {
+// slot m now holds corr[2m] + i corr[2m+1]: its statistics start, the slots behind it are cleared for the Hilbert
+// transform, which finds its input in place, and every thread keeps the samples it will need again for the envelope in
+// registers (the transform overwrites them, and two workgroups' buffers leave no LDS for a copy).  The correlation goes
+// to global memory only when somebody wants it (corr_w: the chain's raw correlation for echo_chain_wave).
+struct FceKeep { zc x[kEnvIterN]; };
+ECHO_HD EnvPart1 ph_fce_corr_out(int tid, int nt, int blk, const EnvParams& p, unsigned char* smem, FceKeep& keep) {
     zc* z = reinterpret_cast<zc*>(smem);
-    double* out = p.corr_w + (size_t)blk * p.L;
+    double* out = p.corr_w ? p.corr_w + (size_t)blk * p.L : nullptr;
     EnvPart1 a;
     a.v[0] = 0.0; a.v[1] = -INFINITY; a.v[2] = INFINITY; a.v[3] = 0.0; a.v[4] = 0.0; a.v[5] = 0.0; a.v[6] = 0.0;
-    for (int m = tid; m < p.n; m += nt) {
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) { keep.x[t] = zc{0.0, 0.0}; continue; }
         const zc x = z[zl(m)];
-        *reinterpret_cast<zc*>(out + 2 * m) = x;
+        keep.x[t] = x;
+        if (out) *reinterpret_cast<zc*>(out + 2 * m) = x;
         const double a0 = fabs(x.x), a1 = fabs(x.y);
         a.v[3] += x.x + x.y; a.v[4] += x.x * x.x + x.y * x.y;
         a.v[5] = a0 > a.v[5] ? a0 : a.v[5]; a.v[5] = a1 > a.v[5] ? a1 : a.v[5];
@@ -252,10 +258,24 @@ ECHO_HD EnvPart1 ph_fce_corr_out(int tid, int nt, int blk, const EnvParams& p, u
     for (int m = p.n + tid; m < kLinH; m += nt) z[zl(m)] = zc{0.0, 0.0};
     return a;
 }
+// envelope[i] = |x[i] + i H(x)[i]| into buffer 1, x from the registers
+ECHO_HD void ph_fce_abs(int tid, int nt, const EnvParams& p, unsigned char* smem, const FceKeep& keep) {
+    const zc* v = reinterpret_cast<const zc*>(smem);
+    double* env = reinterpret_cast<double*>(env_buf(smem, p, 1));
+#pragma unroll
+    for (int t = 0; t < kEnvIterN; ++t) {
+        const int m = tid + t * nt;
+        if (m >= p.n) continue;
+        const zc h = v[zl(m)];
+        env[2 * m] = hypot(keep.x[t].x, h.x);
+        env[2 * m + 1] = hypot(keep.x[t].y, h.y);
+    }
+}
 
-#define ECHO_FCE_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, p, smem, blk, nt)                              \
+#define ECHO_FCE_SEQUENCE(PHASE, SYNC, PART1_DECL, PART1_REF, KEEP_DECL, KEEP_REF, p, smem, blk, nt)         \
     do {                                                                                                     \
         PART1_DECL;                                                                                          \
+        KEEP_DECL;                                                                                           \
         int cur_ = 0;                                                                                        \
         PHASE(ph_fce_stage(tid, nt, blk, p, smem)) SYNC                                                      \
         PHASE(ph_fce_fir(tid, nt, p, smem)) SYNC                                                             \
@@ -268,9 +288,10 @@ ECHO_HD EnvPart1 ph_fce_corr_out(int tid, int nt, int blk, const EnvParams& p, u
         PHASE(ph_envlin_pass<kFceH, 9, 576, true>(tid, nt, (p).fce_tw + kFceTw1, smem)) SYNC                 \
         PHASE(ph_envlin_pass<kFceH, 4, 2304, true>(tid, nt, (p).fce_tw, smem)) SYNC                          \
         if ((p).stop_after == 21) break;                                                                     \
-        PHASE(PART1_REF = ph_fce_corr_out(tid, nt, blk, p, smem)) SYNC                                       \
+        PHASE(PART1_REF = ph_fce_corr_out(tid, nt, blk, p, smem, KEEP_REF)) SYNC                             \
         if ((p).stop_after == 6) break;                                                                      \
         ECHO_ENV_LIN_HILBERT(PHASE, SYNC, p, smem, blk, nt)                                                  \
+        PHASE(ph_fce_abs(tid, nt, p, smem, KEEP_REF)) SYNC                                                   \
         cur_ ^= 1;                                                                                           \
         ECHO_ENV_TAIL(PHASE, SYNC, PART1_REF, p, smem, blk, nt);                                             \
     } while (0)

@@ -346,11 +346,12 @@ extern "C" int emul_fce(int N, int M, int K, int nb, int min_delay, const double
     unsigned char* s = smem.data();
     const int nt = kEnvNT;
     std::vector<EnvPart1> part(nt);
+    std::vector<FceKeep> keep(nt);
 #define PHASE(...) for (int tid = 0; tid < nt; ++tid) { __VA_ARGS__; }
 #define SYNC
     for (int blk = 0; blk < B * nb; ++blk) {
         std::memset(s, 0xff, smem.size());
-        ECHO_FCE_SEQUENCE(PHASE, SYNC, (void)0, part[tid], p, s, blk, nt);
+        ECHO_FCE_SEQUENCE(PHASE, SYNC, (void)0, part[tid], (void)0, keep[tid], p, s, blk, nt);
     }
 #undef PHASE
 #undef SYNC
