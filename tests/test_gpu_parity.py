@@ -192,6 +192,27 @@ def test_chain_with_other_frame_lengths_vs_oracle(kind, listen, chirp):
     e.close()
 
 
+@pytest.mark.parametrize("n_rx,n_chirp,taps", [(3000, 275, 61), (3500, 501, 61), (4282, 327, 61), (4282, 275, 31),
+                                               (4100, 275, 101)])
+def test_full_chain_fused_kernel_with_other_sizes(n_rx, n_chirp, taps):
+    """The fused FIR + correlation + envelope kernel of the full chain takes every even correlation length from 3072
+    to 4608 lags (the shortest here is 3274, the longest 4608 exactly) and other FIR lengths: its staging, the zero
+    padding of its two transforms and the tap groups move with them.  Against the oracle's full chain (indices and
+    validity exact), the fused and the two-kernel form giving the same indices."""
+    from dataclasses import replace
+    from dsp_amd.engine import EchoEngine
+    cfg = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=(n_rx + 0.5) / 48000,
+                  CHIRP_LEN_FIXED=(n_chirp + 0.5) / 48000, FIR_TAPS=taps)
+    assert (cfg.n_rx, cfg.n_chirp, cfg.n_corr % 2) == (n_rx, n_chirp, 0)
+    e = EchoEngine(cfg)
+    t = e.tables
+    rx = synth_frames(48, cfg, t.tx_pcm, start=31)
+    rx[5] = 0.0                                            # silence: no envelope peak, first_strong_peak's None
+    rec, _ = e.chain(rx, mode="full")
+    check_records(_rec(rec), O.chain(rx, t.chirps_f32, t.filters, cfg, mode="full"))
+    e.close()
+
+
 def test_full_chain_with_a_correlation_length_whose_half_is_prime():
     """M = 281 with the default frame gives L = 4562 = 2 * 2281 (prime): the Hilbert transform of the correlation's
     envelope branch then runs its half-length FFTs as Bluestein convolutions.  Full chain (peak indices, validity,

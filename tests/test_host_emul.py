@@ -476,3 +476,28 @@ def test_emulated_fused_full_chain_kernel(emul, gold_default):
             want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
             assert (want, len(pk)) == (peak[f, b], npk[f, b])
             assert abs(qual - q[f, b]) <= 1e-9 and abs(amp[f, b] - scale) <= 1e-13 * scale
+    # other sizes: the shortest correlation the fused kernel takes upward, the longest (4608 lags exactly), other taps
+    from dataclasses import replace
+    from dsp_amd.synth import synth_frames
+    for n_rx, n_chirp, ntaps in ((3000, 275, 61), (4282, 327, 61), (4100, 275, 101)):
+        cfg2 = replace(C.optimized_config(C.BANDS_DISTINCT), LISTEN_LEN_FIXED=(n_rx + 0.5) / 48000,
+                       CHIRP_LEN_FIXED=(n_chirp + 0.5) / 48000, FIR_TAPS=ntaps)
+        t2 = build_tables(cfg2)
+        rx2 = synth_frames(2, cfg2, t2.tx_pcm, start=3)
+        y2 = np.ascontiguousarray(np.stack([[filtfilt(f[0], f[1], x) for f in t2.filters] for x in rx2]))
+        taps2 = np.ascontiguousarray(t2.taps); chirps2 = np.ascontiguousarray(t2.chirps)
+        corr2 = np.zeros((2, nb, cfg2.n_corr)); bandf2 = np.zeros((2, nb, cfg2.n_rx), np.float32)
+        peak2 = np.zeros((2, nb), np.int32); npk2 = np.zeros((2, nb), np.int32)
+        snr2 = np.zeros((2, nb)); amp2 = np.zeros((2, nb)); q2 = np.zeros((2, nb))
+        assert emul.emul_fce(cfg2.n_rx, cfg2.n_chirp, ntaps, nb, cfg2.min_delay, _ptr(taps2), _ptr(chirps2), _ptr(y2), 2,
+                             _ptr(corr2), _ptr(bandf2), _ptr(peak2), _ptr(snr2), _ptr(amp2), _ptr(q2), _ptr(npk2)) == 0
+        for f in range(2):
+            for b in range(nb):
+                band = O.bandpass(rx2[f], t2.filters[b])
+                rc = O.gpu_correlate(band, t2.chirps_f32[b])
+                assert np.abs(bandf2[f, b] - band).max() <= 1e-6 * np.abs(band).max()
+                assert np.abs(corr2[f, b] - rc).max() <= 1e-13 * np.abs(rc).max()
+                e, pk, qual = O.gpu_envelope_detection(rc, 5)
+                vp = pk[pk >= cfg2.min_delay]
+                want = int(vp[np.argmax(e[vp])]) if len(vp) else -1
+                assert (want, len(pk)) == (peak2[f, b], npk2[f, b]) and abs(qual - q2[f, b]) <= 1e-9
