@@ -34,9 +34,6 @@ using zc = cpx<double>;
 ECHO_HD zc zc_mul(zc a, zc b) { return zc{fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)}; }
 ECHO_HD zc zc_mulc(zc a, zc b) { return zc{fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y))}; }   // a * conj(b)
 
-// Tables: tw = pass twiddles, for the pass on blocks of S elements with radix R and stride q = S / R the runs
-// tw[off + (m - 1) q + i] = exp(-2 pi i (i m) / S), 1 <= m < R, i < q (the last pass has q = 1: none);
-// wk[k] = exp(-2 pi i k / F2), k <= H;  gam[k] = Im(DFT_F2(kernel))[k] / H, k <= H.
 // lane order of the middle phase: item t = (d2 = t & 3, d1 = (t >> 2) & 7, d0 = t >> 5) is the residue d0 + 9 d1 + 72 d2
 inline int envlin_mid_residue(int t) { return (t >> 5) + 9 * ((t >> 2) & 7) + 72 * (t & 3); }
 // wmid[d * 288 + t] = wk[k], gmid[d * 288 + t] = (gam[k], gam[H - k]) for k = residue(t) + 576 d: what the middle phase
@@ -51,6 +48,9 @@ inline void envlin_mid_tables(const std::vector<zc>& wk, const std::vector<doubl
             gmid[d * 288 + t] = zc{gam[k], gam[kLinH - k]};
         }
 }
+// Tables: tw = pass twiddles, for the pass on blocks of S elements with radix R and stride q = S / R the runs
+// tw[off + (m - 1) q + i] = exp(-2 pi i (i m) / S), 1 <= m < R, i < q (the last pass has q = 1: none);
+// wk[k] = exp(-2 pi i k / F2), k <= H;  gam[k] = Im(DFT_F2(kernel))[k] / H, k <= H.
 inline void envlin_tables(int L, std::vector<zc>& tw, std::vector<zc>& wk, std::vector<double>& gam) {
     const long double tau = 6.283185307179586476925286766559005768L;
     tw.clear();
