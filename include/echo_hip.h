@@ -116,8 +116,9 @@ typedef struct EchoHandle EchoHandle;
  * spectra as direct float64 sums, O(n_rx^2) per frame and band.  Correlations of up to 4608 lags (n_rx + n_chirp - 1; the reference's constants give 4556) with the
  * median or mean-power detector run on single-workgroup kernels; anything longer, and the MAD and two-peak detectors,
  * on tiled kernels (every detector; echo_chain_full and echo_envelope_detection are then ECHO_ERR_UNSUPPORTED).
- * echo_chain_full takes every even correlation length of the single-workgroup kernels: where half of it has a large prime
- * factor (e.g. 4562 = 2 * 2281) the Hilbert transform runs as Bluestein convolutions, as in echo_envelope_rows.
+ * echo_chain_full takes every even correlation length of the single-workgroup kernels: from 3072 lags on the Hilbert
+ * transform is one real cyclic convolution of length 9216, whatever the factors of the length (4562 = 2 * 2281 included);
+ * shorter ones take half-length transforms (Bluestein convolutions where the half has a large prime factor).
  * iir_ncoef = 1 with n_taps = 1 is the identity filter ([1], [1], [1]) design_filters falls back to (:178-182); zi may
  * then be NULL.  ECHO_ERR_UNSUPPORTED from echo_create: IIR order other than 0, 6 or 8 (iir_ncoef 1 / 13 / 17), or a frame so long that one
  * frame's detector input exceeds a workgroup's 160 KB of LDS (about 20,000 lags). */
@@ -197,8 +198,9 @@ int echo_envelope_detection(EchoHandle* h, const double* corr, double* envelope,
 /* gpu_envelope_detection(signal, 'hilbert', smooth_window) on arbitrary rows (airSonar_optimized.py:431-475), e.g. the
  * band-signal call with smooth_window = 3 (:636, :708): x[rows][len] float64, len even; smooth_window odd, 1..9.
  * Outputs as echo_envelope_detection, per row; peak_idx / snr_db apply `min_delay` the way :647-654 do (pass 0 when
- * only envelope, peaks and quality are wanted).  Lengths whose half has a large prime factor (4282 = 2 * 2141) run the
- * Hilbert transform as Bluestein convolutions.  ECHO_ERR_UNSUPPORTED: odd or very short len, even smooth_window, or a
+ * only envelope, peaks and quality are wanted).  Rows of 3072 to 4608 samples run the Hilbert transform as one real cyclic
+ * convolution of length 9216; other lengths as two half-length transforms (Bluestein convolutions where the half has a
+ * large prime factor).  ECHO_ERR_UNSUPPORTED: odd or very short len, even smooth_window, or a
  * transform that does not fit one workgroup's LDS (len beyond about 4700).  Allocates its plan on first use. */
 int echo_envelope_rows(EchoHandle* h, const double* x, int len, int smooth_window, int min_delay, double* envelope,
                        int32_t* peak_idx, double* snr_db, double* quality, int32_t* n_peaks, int32_t* peaks, int rows,
