@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 FRAMES_PER_STEP = 4096          # BASELINE.json configs[1]
 N_STREAMS = 64                  # 64 streams x 64 time steps per batch for the Kalman stage
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
+PREWARM_STEPS = 40              # untimed steps ahead of the warm-up steps (GPU clock ramp), see main()
 
 
 def parse():
@@ -281,13 +282,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The GPU's clocks ramp for tens of milliseconds after the first kernels of a process; W warm-up steps of about a
+    # millisecond each do not cover that (measured: 3.40-3.48 M frames/s over 20 timed steps behind 5 warm-up steps,
+    # 3.57 M behind 50).  The untimed steps below keep the GPU busy before the W warm-up steps start; they are part of
+    # neither W nor K and are reported as `gpu_prewarm_steps`.
+    prewarm = 0 if strong else PREWARM_STEPS
+    for _ in range(prewarm):
+        step()
+    if prewarm:
+        fence()
+    kms_serial = None
+    prof_on = not args.no_kernel_timing
+    if lanes is not None and prof_on and not strong:
+        # outside the timed region: the same kernels one after the other on one stream, every call timed.  With several
+        # batches in flight a kernel's duration above is stretched by the other lanes' kernels running beside it;
+        # these are the durations each kernel has with the GPU to itself.
+        eng.set_profiling(6)
+        rec_x = torch.empty((B, 64), dtype=torch.uint8, device=dev)
+        for _ in range(6):
+            eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), want_spectra=want_spec, out=rec_x, spec_out=specs[0],
+                      mode=args.mode)
+        torch.cuda.synchronize(dev)
+        kms_serial = eng.last_kernel_ms()
+        eng.set_profiling(0)
     for _ in range(args.warmup):
         step()
     fence()
     # kernel durations by HIP events on the calls' own streams, inside the timed region.  Event records keep a stream's
     # kernels from running back to back, so only a sample of the calls is timed: every eighth call of the first lane
     # (every call on a single stream).
-    prof_on = not args.no_kernel_timing
     if prof_on:
         eng.set_profiling(min(args.steps, 64), every=8 if lanes is not None else 1)
     t0 = time.perf_counter()
@@ -301,19 +324,6 @@ def main():
     if pipeline:
         kms["iir_wait"] = kms["iir"]           # on the caller's stream only the wait for the prefetched IIR remains
         kms["iir"] = eng.prefetch_ms()         # device time of the IIR kernel on the engine's stream
-    kms_serial = None
-    if lanes is not None and prof_on and not strong:
-        # outside the timed region: the same kernels one after the other on one stream, every call timed.  With several
-        # batches in flight a kernel's duration above is stretched by the other lanes' kernels running beside it;
-        # these are the durations each kernel has with the GPU to itself.
-        eng.set_profiling(6)
-        rec_x = torch.empty((B, 64), dtype=torch.uint8, device=dev)
-        for _ in range(6):
-            eng.chain(rx, n_streams=S, kalman=BatchedKalman(eng, S), want_spectra=want_spec, out=rec_x, spec_out=specs[0],
-                      mode=args.mode)
-        torch.cuda.synchronize(dev)
-        kms_serial = eng.last_kernel_ms()
-        eng.set_profiling(0)
     steady = None
     if lanes is not None and not strong and not use_dist:
         # Beside the fenced wall-clock value, never instead of it: the rate between the completion of two batches of
@@ -418,6 +428,7 @@ def main():
                          "as_benched": as_benched},
             "kernel_ms": kms,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
+            "gpu_prewarm_steps": prewarm,
         }
         if kms_serial is not None:
             cs = {"iir": kms_serial["iir"], "spec": kms_serial["spec"]}
@@ -430,7 +441,7 @@ def main():
             out["roofline"]["dominant_kernel_alone"] = {
                 "kernel": names[ds], "kernel_ms": cs[ds], "achieved": a2, "frac": a2 / HBM_PEAK_GBPS,
                 "traffic": per_kernel_traffic.get(ds), "kernel_ms_all": kms_serial,
-                "note": "measured after the timed region: 6 calls on one stream, nothing overlapped"}
+                "note": "measured before the warm-up steps: 6 calls on one stream, nothing overlapped"}
         if steady is not None:
             out["steady_state"] = steady
         if strong:
