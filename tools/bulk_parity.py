@@ -5,6 +5,7 @@ replays the Kalman filter over the oracle's fused ranges and writes a JSON summa
 Usage: bulk_parity.py [frames] [workers] [out.json] [lanes] [variant]; exits non-zero on any index or validity
 mismatch.  variant: optimized (default: both band sets, named and full chain), or original / twopeak / realtime (the
 other parameter sets, named chain).
+BULK_START=<index> moves the run to another range of synthetic frames (default 100000).
 With lanes > 1 the GPU side runs as batches of 4096 frames in flight on that many streams (ChainLanes), which also
 checks that concurrent handles do not disturb each other."""
 import json
@@ -17,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-START = 100000
+START = int(os.environ.get("BULK_START", "100000"))   # index of the first synthetic frame (frame i is a function of seed + i)
 CHUNK = 500
 
 
@@ -65,7 +66,11 @@ def main():
         for which, modes in legs:
             cfg = _config(which)
             eng = EchoEngine(cfg)
-            rx = synth_frames(n, cfg, eng.tables.tx_pcm, start=START)
+            rx = np.empty((n, cfg.n_rx), dtype=np.float32)
+            for lo in range(0, n, 50000):                       # in pieces, with a sign of life for long runs
+                hi = min(n, lo + 50000)
+                rx[lo:hi] = synth_frames(hi - lo, cfg, eng.tables.tx_pcm, start=START + lo)
+                print(f"  {which}: frames {hi}/{n} generated", flush=True)
             for mode in modes:
                 t0 = time.time()
                 jobs = [(which, mode, lo, min(CHUNK, n - lo)) for lo in range(0, n, CHUNK)]
