@@ -368,6 +368,57 @@ __device__ __forceinline__ void ex_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The wavefront exchanges of the exact kernel.  Device pass only: the host pass of this file never runs a kernel body and
+// gets declarations that return their arguments.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Value of lane ^ O: a DPP move where one control expresses the exchange (inside a quad, across the halves of a row of
+// 16 lanes), a shuffle through the LDS crossbar otherwise.  O must be a compile-time constant after unrolling.
+__device__ __forceinline__ double ex_xor(double v, int o) {
+    switch (o) {
+        case 1: return wave_fold_dpp<0xB1>(v);               // quad_perm [1,0,3,2]
+        case 2: return wave_fold_dpp<0x4E>(v);               // quad_perm [2,3,0,1]
+        case 8: return wave_fold_dpp<0x128>(v);              // row_ror:8
+        default: return __shfl_xor(v, o);
+    }
+}
+template <int CTRL> __device__ __forceinline__ int ex_dpp_int(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
+// Fold of an int over the wavefront, every lane gets the result (MAX: maximum, else minimum): four DPP exchanges inside
+// the rows of 16 lanes, then the four rows' results as scalar lane reads.
+template <bool MAX> __device__ __forceinline__ int ex_fold_int(int v) {
+    int t;
+    t = ex_dpp_int<0xB1>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+    t = ex_dpp_int<0x4E>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+    t = ex_dpp_int<0x141>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+    t = ex_dpp_int<0x140>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
+              r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = MAX ? (r1 > r0 ? r1 : r0) : (r1 < r0 ? r1 : r0), b = MAX ? (r3 > r2 ? r3 : r2) : (r3 < r2 ? r3 : r2);
+    return MAX ? (b > a ? b : a) : (b < a ? b : a);
+}
+// The detector partials of a wavefront folded into every lane: signed maximum with the lower index among equals
+// (a total order, so the result does not depend on the order of the exchanges) and max|corr|.
+template <int CTRL> __device__ __forceinline__ void ex_fold_step(double& b, int& bi, double& am) {
+    const double b2 = wave_fold_dpp<CTRL>(b); const int i2 = ex_dpp_int<CTRL>(bi);
+    combine(b, bi, b2, i2);
+    const double a2 = wave_fold_dpp<CTRL>(am); am = a2 > am ? a2 : am;
+}
+__device__ __forceinline__ void ex_fold_det(double& b, int& bi, double& am) {
+    ex_fold_step<0xB1>(b, bi, am); ex_fold_step<0x4E>(b, bi, am); ex_fold_step<0x141>(b, bi, am); ex_fold_step<0x140>(b, bi, am);
+    double rb = wave_fold_lane(b, 0), ra = wave_fold_lane(am, 0);
+    int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int row = 16; row < 64; row += 16) {
+        combine(rb, ri, wave_fold_lane(b, row), __builtin_amdgcn_readlane(bi, row));
+        const double a2 = wave_fold_lane(am, row); ra = a2 > ra ? a2 : ra;
+    }
+    b = rb; bi = ri; am = ra;
+}
+#else
+__device__ inline double ex_xor(double v, int) { return v; }
+template <bool MAX> __device__ inline int ex_fold_int(int v) { return v; }
+__device__ inline void ex_fold_det(double&, int&, double&) {}
+#endif
+
 // One 8-byte read of LDS that the compiler neither merges with its neighbours nor widens to a flat access.
 typedef const volatile __attribute__((address_space(3))) double lds_cv_f64;
 __device__ __forceinline__ double lds_read_f64(const double* p) { return *(lds_cv_f64*)p; }
@@ -437,12 +488,7 @@ __device__ __forceinline__ void exact_segment(const BandParams& p, const ExView&
         am = a > am ? a : am;
         if (k >= kstart && x > b) { b = x; bi = qd; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double b2 = __shfl_xor(b, o); const int i2 = __shfl_xor(bi, o);
-        combine(b, bi, b2, i2);
-        const double a2 = __shfl_xor(am, o); am = a2 > am ? a2 : am;
-    }
+    ex_fold_det(b, bi, am);
     combine(best, bidx, b, bi);
     amp = am > amp ? am : amp;
 }
@@ -482,21 +528,19 @@ __global__ __launch_bounds__(kExNT) void exact_kernel(BandParams p, int nfb) {
     } else {
         int done_below = 0;                                    // lags below it have been evaluated
         for (;;) {
-            int lo = mine >= done_below ? mine : 0x7fffffff;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(lo, o); lo = t < lo ? t : lo; }
+            const int lo = ex_fold_int<false>(mine >= done_below ? mine : 0x7fffffff);
             if (lo == 0x7fffffff) break;
             // how far the listed lags reach from lo inside one segment
-            int hi = (mine >= lo && mine < lo + kB2Seg) ? mine : lo;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(hi, o); hi = t > hi ? t : hi; }
+            const int hi = ex_fold_int<true>((mine >= lo && mine < lo + kB2Seg) ? mine : lo);
             if (hi - lo >= 16) exact_segment<9, 5>(p, v, y, lo, hi - lo + 1, lane, best, bidx, amp);
             else exact_segment<5, 1>(p, v, y, lo, hi - lo + 1, lane, best, bidx, amp);
             done_below = hi + 1;
         }
     }
     // ---- median of the noise window (np.median: mean of the two middle order statistics): the window, padded with
-    // +inf to 256 values, four per lane, sorted by a bitonic network in registers
+    // +inf to 256 values, four per lane, sorted by a bitonic network in registers.  Compare and select (the values are
+    // magnitudes or +inf: equal values are the same bits, so either choice among equals gives the same sequence); the
+    // minimum / maximum instructions would first have to canonicalise each operand.
 #pragma unroll
     for (int k = 2; k <= 256; k <<= 1) {
 #pragma unroll
@@ -505,10 +549,9 @@ __global__ __launch_bounds__(kExNT) void exact_kernel(BandParams p, int nfb) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = lane * 4 + e;
-                    const double o = __shfl_xor(x[e], j >> 2);
-                    const bool lower = (i & j) == 0, asc = (i & k) == 0;
-                    const double mn = fmin(x[e], o), mx = fmax(x[e], o);
-                    x[e] = (lower == asc) ? mn : mx;
+                    const double o = ex_xor(x[e], j >> 2);
+                    const bool want_min = ((i & j) == 0) == ((i & k) == 0);
+                    x[e] = ((o < x[e]) == want_min) ? o : x[e];
                 }
             } else {
 #pragma unroll
@@ -517,8 +560,8 @@ __global__ __launch_bounds__(kExNT) void exact_kernel(BandParams p, int nfb) {
                     const int i = lane * 4 + e;
                     const bool asc = (i & k) == 0;
                     const double a = x[e], b = x[e | j];
-                    const double mn = fmin(a, b), mx = fmax(a, b);
-                    x[e] = asc ? mn : mx; x[e | j] = asc ? mx : mn;
+                    const bool sw = (b < a) == asc;
+                    x[e] = sw ? b : a; x[e | j] = sw ? a : b;
                 }
             }
         }
