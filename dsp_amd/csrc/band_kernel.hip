@@ -143,12 +143,7 @@ __device__ __forceinline__ void bluestein9_round(int tid, const BandParams& p, u
 __device__ __forceinline__ void b2_reduce4(double (&v)[4], const int (&ops)[4], double* red, int area, int tid) {
     constexpr int kWaves = kF9NT / 64;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double x = __shfl_xor(v[q], o);
-            v[q] = ops[q] ? (x > v[q] ? x : v[q]) : v[q] + x;
-        }
+    for (int q = 0; q < 4; ++q) v[q] = wave_fold(ops[q] ? 1 : 0, v[q]);     // DPP moves and lane reads, no LDS round trips
     double* r = red + area * kWaves * 4;
     if ((tid & 63) == 0)
         for (int q = 0; q < 4; ++q) r[(tid >> 6) * 4 + q] = v[q];
